@@ -1,0 +1,77 @@
+"""ctypes binding of libdsmnet_hip.so (the C ABI of include/dsmnet_hip.h).
+
+This is the whole reference-side binding: the reference is Python, so a
+maintainer who wants the MI355X path adds exactly this stub.
+There is no CPU fallback: if the library is missing the import of any op raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdsmnet_hip.so")
+
+c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+
+DSM_OK = 0
+DSM_F32 = 0
+DSM_NCDHW, DSM_NDHWC = 0, 1
+
+
+class Conv3dArgs(ctypes.Structure):
+    """struct dsm_conv3d_args (include/dsmnet_hip.h)."""
+    _fields_ = [("x", c_void_p), ("w_packed", c_void_p), ("scale", c_void_p),
+                ("shift", c_void_p), ("residual", c_void_p), ("y", c_void_p),
+                ("B", c_int), ("Cin", c_int), ("Cout", c_int),
+                ("Di", c_int), ("Hi", c_int), ("Wi", c_int),
+                ("Do", c_int), ("Ho", c_int), ("Wo", c_int),
+                ("Dr", c_int), ("Hr", c_int), ("Wr", c_int),
+                ("stride", c_int), ("transposed", c_int), ("relu", c_int)]
+
+
+# name -> (restype, argtypes); must list every symbol declared in dsmnet_hip.h
+SIGNATURES = {
+    "dsm_abi_version": (c_int, []),
+    "dsm_strerror": (ctypes.c_char_p, [c_int]),
+    "dsm_corr1d_fwd": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
+    "dsm_corr1d_bwd": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
+    "dsm_concat_volume_fwd": (c_int, [c_void_p] * 3 + [c_int] * 8 + [c_void_p]),
+    "dsm_concat_volume_bwd": (c_int, [c_void_p] * 3 + [c_int] * 8 + [c_void_p]),
+    "dsm_soft_argmin_fwd": (c_int, [c_void_p] * 3 + [c_int] * 10 + [c_void_p]),
+    "dsm_soft_argmin_bwd": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
+    "dsm_conv3d_packed_weight_bytes": (c_size_t, [c_int] * 3),
+    "dsm_conv3d_pack_weights": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
+    "dsm_conv3d_fwd": (c_int, [ctypes.POINTER(Conv3dArgs), c_void_p]),
+    "dsm_volume_relayout": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
+}
+
+_lib = None
+
+
+class DsmnetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DsmnetHipError(
+            "libdsmnet_hip.so not found at %s -- build it with "
+            "`python -m dsmnet_amd.csrc.build` (there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dsm_abi_version() != 1:
+        raise DsmnetHipError("libdsmnet_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != DSM_OK:
+        msg = load().dsm_strerror(code).decode()
+        raise DsmnetHipError("%s failed: %s (code %d)" % (what, msg, code))

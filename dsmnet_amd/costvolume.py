@@ -1,0 +1,280 @@
+"""Stereo cost-volume ops of the DSMnet path as ``torch.autograd.Function``s.
+
+Every op is a thin host wrapper over the C ABI of ``include/dsmnet_hip.h``
+(``libdsmnet_hip.so``, hand-written HIP for gfx950), launched on PyTorch's
+current HIP stream.  PyTorch is plumbing here: device memory, streams, autograd
+book-keeping.  There is no CPU path -- CPU tensors raise.
+
+Reference code each op replaces (sunshinnnn/DSMnet):
+  corr1d          models/util_conv.py:56-86           (Corr1d)
+  concat_volume   models/gcnet.py:130-135, models/psmnet/stackhourglass.py:124-133
+  soft_argmin     models/psmnet/stackhourglass.py:152-166 + submodule.py:56-63,
+                  models/gcnet.py:104-111
+  conv3d_block    models/psmnet/submodule.py:16-19, stackhourglass.py:22-62,
+                  models/util_conv.py:150-179, models/util_fun.py:41-50
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_CL3D = torch.channels_last_3d
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _require_device(name, *tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "%s: dsmnet_amd ops run on the MI355X through libdsmnet_hip.so only; got a %s "
+                "tensor (there is no CPU fallback)" % (name, t.device.type))
+        if t.dtype != torch.float32:
+            raise TypeError("%s: only float32 is implemented, got %s" % (name, t.dtype))
+
+
+def _same_shape(name, a, b):
+    if a.shape != b.shape:
+        # the reference asserts this in its model forwards (gcnet.py:127, dispnetcorr.py:67)
+        raise ValueError("%s: left/right feature shapes differ: %s vs %s"
+                         % (name, tuple(a.shape), tuple(b.shape)))
+
+
+# ----------------------------------------------------------------------------
+# (a1) Corr1d
+# ----------------------------------------------------------------------------
+class Corr1dFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fL, fR, D, stride, kernel_size):
+        _require_device("corr1d", fL, fR)
+        if fL.dim() != 4:
+            raise ValueError("corr1d: expected (B,C,H,W) features, got %d-D" % fL.dim())
+        _same_shape("corr1d", fL, fR)
+        if kernel_size % 2 != 1:
+            raise AssertionError("kernel_size must be odd")      # util_conv.py:83
+        fL, fR = fL.contiguous(), fR.contiguous()
+        B, C, H, W = fL.shape
+        out = torch.empty((B, D, H, W), device=fL.device, dtype=fL.dtype)
+        tmp = torch.empty_like(out) if kernel_size > 1 else None
+        lib = _lib.load()
+        with torch.cuda.device(fL.device):
+            rc = lib.dsm_corr1d_fwd(_p(fL), _p(fR), _p(out), _p(tmp), B, C, H, W, D, stride,
+                                    kernel_size, _lib.DSM_F32, _stream())
+        _lib.check(rc, "dsm_corr1d_fwd")
+        ctx.save_for_backward(fL, fR)
+        ctx.cfg = (D, stride, kernel_size)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        fL, fR = ctx.saved_tensors
+        D, stride, kernel_size = ctx.cfg
+        g = grad_out.contiguous()
+        B, C, H, W = fL.shape
+        dfL, dfR = torch.empty_like(fL), torch.empty_like(fR)
+        tmp = torch.empty_like(g) if kernel_size > 1 else None
+        lib = _lib.load()
+        with torch.cuda.device(fL.device):
+            rc = lib.dsm_corr1d_bwd(_p(g), _p(fL), _p(fR), _p(dfL), _p(dfR), _p(tmp), B, C, H, W,
+                                    D, stride, kernel_size, _lib.DSM_F32, _stream())
+        _lib.check(rc, "dsm_corr1d_bwd")
+        return dfL, dfR, None, None, None
+
+
+def corr1d(fL, fR, D, stride=1, kernel_size=1):
+    """``Corr1d(kernel_size, stride, D).forward(fL, fR)`` -> (B, D, H, W)."""
+    return Corr1dFunction.apply(fL, fR, int(D), int(stride), int(kernel_size))
+
+
+# ----------------------------------------------------------------------------
+# (a2, a3) concatenation cost volume
+# ----------------------------------------------------------------------------
+class ConcatVolumeFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fL, fR, D, mask_left, channels_last):
+        _require_device("concat_volume", fL, fR)
+        if fL.dim() != 4:
+            raise ValueError("concat_volume: expected (B,C,H,W) features, got %d-D" % fL.dim())
+        _same_shape("concat_volume", fL, fR)
+        fL, fR = fL.contiguous(), fR.contiguous()
+        B, C, H, W = fL.shape
+        fmt = _CL3D if channels_last else torch.contiguous_format
+        vol = torch.empty((B, 2 * C, D, H, W), device=fL.device, dtype=fL.dtype,
+                          memory_format=fmt)
+        layout = _lib.DSM_NDHWC if channels_last else _lib.DSM_NCDHW
+        lib = _lib.load()
+        with torch.cuda.device(fL.device):
+            rc = lib.dsm_concat_volume_fwd(_p(fL), _p(fR), _p(vol), B, C, H, W, D,
+                                           int(mask_left), layout, _lib.DSM_F32, _stream())
+        _lib.check(rc, "dsm_concat_volume_fwd")
+        ctx.cfg = (B, C, H, W, D, int(mask_left), layout, fmt)
+        return vol
+
+    @staticmethod
+    def backward(ctx, gvol):
+        B, C, H, W, D, mask_left, layout, fmt = ctx.cfg
+        g = gvol.contiguous(memory_format=fmt)
+        dfL = torch.empty((B, C, H, W), device=g.device, dtype=g.dtype)
+        dfR = torch.empty_like(dfL)
+        lib = _lib.load()
+        with torch.cuda.device(g.device):
+            rc = lib.dsm_concat_volume_bwd(_p(g), _p(dfL), _p(dfR), B, C, H, W, D, mask_left,
+                                           layout, _lib.DSM_F32, _stream())
+        _lib.check(rc, "dsm_concat_volume_bwd")
+        return dfL, dfR, None, None, None
+
+
+def concat_volume(fL, fR, D, mask_left, channels_last=True):
+    """Concatenation cost volume (B, 2C, D, H, W).
+
+    ``mask_left=False``: GCNet (gcnet.py:130-135); ``True``: PSMNet
+    (stackhourglass.py:124-133).  ``channels_last`` selects the memory format of the
+    result: ``torch.channels_last_3d`` (what ``conv3d_block`` consumes) or contiguous."""
+    return ConcatVolumeFunction.apply(fL, fR, int(D), bool(mask_left), bool(channels_last))
+
+
+# ----------------------------------------------------------------------------
+# (a6, a7) soft-argmin
+# ----------------------------------------------------------------------------
+class SoftArgminFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost, out_size, negate, align_corners):
+        _require_device("soft_argmin", cost)
+        if cost.dim() == 5:
+            if cost.shape[1] != 1:
+                raise ValueError("soft_argmin: 5-D cost must have one channel")
+            c4 = cost.reshape(cost.shape[0], *cost.shape[2:])
+        elif cost.dim() == 4:
+            c4 = cost
+        else:
+            raise ValueError("soft_argmin: expected (B,1,D,H,W) or (B,D,H,W)")
+        c4 = c4.contiguous()
+        B, Dc, Hc, Wc = c4.shape
+        D, H, W = (Dc, Hc, Wc) if out_size is None else tuple(int(v) for v in out_size)
+        disp = torch.empty((B, H, W), device=cost.device, dtype=cost.dtype)
+        need_grad = ctx.needs_input_grad[0]
+        stats = torch.empty((B, 2, H, W), device=cost.device, dtype=cost.dtype) if need_grad else None
+        lib = _lib.load()
+        with torch.cuda.device(cost.device):
+            rc = lib.dsm_soft_argmin_fwd(_p(c4), _p(disp), _p(stats), B, Dc, Hc, Wc, D, H, W,
+                                         int(negate), int(align_corners), _lib.DSM_F32, _stream())
+        _lib.check(rc, "dsm_soft_argmin_fwd")
+        if need_grad:
+            ctx.save_for_backward(c4, disp, stats)
+        ctx.cfg = (tuple(cost.shape), B, Dc, Hc, Wc, D, H, W, int(negate), int(align_corners))
+        return disp
+
+    @staticmethod
+    def backward(ctx, gdisp):
+        c4, disp, stats = ctx.saved_tensors
+        shape, B, Dc, Hc, Wc, D, H, W, negate, align = ctx.cfg
+        g = gdisp.contiguous()
+        dcost = torch.empty_like(c4)
+        lib = _lib.load()
+        with torch.cuda.device(c4.device):
+            rc = lib.dsm_soft_argmin_bwd(_p(c4), _p(disp), _p(stats), _p(g), _p(dcost), B, Dc, Hc,
+                                         Wc, D, H, W, negate, align, _lib.DSM_F32, _stream())
+        _lib.check(rc, "dsm_soft_argmin_bwd")
+        return dcost.reshape(shape), None, None, None
+
+
+def soft_argmin(cost, out_size=None, negate=False, align_corners=False):
+    """Fused (trilinear upsample ->) softmax over disparity -> expectation.  -> (B, H, W)."""
+    return SoftArgminFunction.apply(cost, out_size, bool(negate), bool(align_corners))
+
+
+# ----------------------------------------------------------------------------
+# (a4, a5) 3-D convolution block
+# ----------------------------------------------------------------------------
+def pack_conv3d_weight(weight, transposed):
+    """torch Conv3d / ConvTranspose3d weight (k=3) -> MFMA fragment order (device)."""
+    _require_device("pack_conv3d_weight", weight)
+    if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3):
+        raise ValueError("conv3d_block supports kernel_size=3 only, got %s" % (tuple(weight.shape),))
+    cin, cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+    w = weight.detach().contiguous()
+    lib = _lib.load()
+    nbytes = lib.dsm_conv3d_packed_weight_bytes(cin, cout, int(transposed))
+    packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        rc = lib.dsm_conv3d_pack_weights(_p(w), _p(packed), cin, cout, int(transposed), _stream())
+    _lib.check(rc, "dsm_conv3d_pack_weights")
+    return packed
+
+
+def to_channels_last_3d(x):
+    """(B,C,D,H,W) in any strides -> NDHWC memory (no copy when it already is)."""
+    if x.is_contiguous(memory_format=_CL3D):
+        return x
+    _require_device("to_channels_last_3d", x)
+    xc = x.contiguous()
+    B, C, D, H, W = xc.shape
+    out = torch.empty((B, C, D, H, W), device=x.device, dtype=x.dtype, memory_format=_CL3D)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().dsm_volume_relayout(_p(xc), _p(out), B, C, D, H, W, 1, _stream())
+    _lib.check(rc, "dsm_volume_relayout")
+    return out
+
+
+def to_contiguous_3d(x):
+    """NDHWC memory -> torch contiguous (B,C,D,H,W)."""
+    if x.is_contiguous():
+        return x
+    if not x.is_contiguous(memory_format=_CL3D):
+        return x.contiguous()
+    B, C, D, H, W = x.shape
+    out = torch.empty((B, C, D, H, W), device=x.device, dtype=x.dtype)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().dsm_volume_relayout(_p(x), _p(out), B, C, D, H, W, 0, _stream())
+    _lib.check(rc, "dsm_volume_relayout")
+    return out
+
+
+def conv3d_out_size(in_size, stride, transposed):
+    if transposed:
+        return tuple(2 * v for v in in_size)          # k3, s2, p1, op1
+    return tuple((v - 1) // stride + 1 for v in in_size)
+
+
+def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, stride=1,
+                 transposed=False, relu=False):
+    """y = relu?(conv(x) * scale + shift (+ residual, cropped to the common size)).
+
+    ``x`` is (B,Cin,D,H,W); it is consumed in NDHWC memory (converted if needed) and
+    the result is returned as a channels_last_3d tensor.  With ``residual`` the output
+    takes the element-wise minimum of the two spatial sizes -- ``myadd_3d`` semantics
+    (stackhourglass.py:10-20).  Inference only (no autograd)."""
+    _require_device("conv3d_block", x, packed_weight, scale, shift, residual)
+    x = to_channels_last_3d(x)
+    B, cin, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = conv3d_out_size((Di, Hi, Wi), stride, transposed)
+    a = _lib.Conv3dArgs()
+    if residual is not None:
+        if residual.shape[0] != B or residual.shape[1] != cout:
+            raise ValueError("conv3d_block: residual has shape %s, expected (%d,%d,...)"
+                             % (tuple(residual.shape), B, cout))
+        residual = to_channels_last_3d(residual)
+        a.Dr, a.Hr, a.Wr = residual.shape[2:]
+        Do, Ho, Wo = min(Do, a.Dr), min(Ho, a.Hr), min(Wo, a.Wr)
+    y = torch.empty((B, cout, Do, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=_CL3D)
+    a.x, a.w_packed, a.y = x.data_ptr(), packed_weight.data_ptr(), y.data_ptr()
+    a.scale = None if scale is None else scale.data_ptr()
+    a.shift = None if shift is None else shift.data_ptr()
+    a.residual = None if residual is None else residual.data_ptr()
+    a.B, a.Cin, a.Cout = B, cin, cout
+    a.Di, a.Hi, a.Wi = Di, Hi, Wi
+    a.Do, a.Ho, a.Wo = Do, Ho, Wo
+    a.stride, a.transposed, a.relu = int(stride), int(transposed), int(relu)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().dsm_conv3d_fwd(ctypes.byref(a), _stream())
+    _lib.check(rc, "dsm_conv3d_fwd")
+    return y

@@ -1,0 +1,581 @@
+// 3-D convolution blocks (k = 3) of the GCNet / PSMNet regularisation trunk on
+// gfx950 matrix cores -- implicit GEMM on v_mfma_f32_32x32x2_f32.
+//
+// Replaces nn.Conv3d / nn.ConvTranspose3d + nn.BatchNorm3d + ReLU + the cropped
+// skip additions of models/psmnet/stackhourglass.py:22-62,73-98,135-149,
+// models/psmnet/submodule.py:16-19, models/gcnet.py:32-101 and
+// models/util_conv.py:150-179 with one launch per layer and a fused epilogue.
+//
+// GEMM view: M = output voxels, N = Cout, K = 27 taps x Cin.  The f32-input MFMA is
+// an exact fp32 fma chain (products and sums rounded once each, no reduced
+// precision), so parity with the reference's fp32 path needs no tolerance beyond
+// summation order; its rate is the fp32 vector rate (157 TF/s dense peak), 1/16 of
+// bf16, which makes the kernel MFMA-issue bound by a wide margin: per MFMA (64
+// cycles per SIMD) a wave needs 16 B of A per lane per 4 MFMAs from LDS and 16 B
+// of B per lane per 4*TM MFMAs from L2.  The design therefore spends nothing on
+// bandwidth tricks and everything on keeping the matrix pipe issuing:
+//
+//  * activations are NDHWC (channels_last_3d), a voxel's channels contiguous;
+//  * a workgroup (4 waves) owns an output tile of 1 z x (4*TM) y x 32 x; wave w
+//    owns TM rows; an M-tile is 32 consecutive x of one row (MFMA rows);
+//  * K is walked in chunks of CK input channels: the chunk's halo tile
+//    (3 x IY x IX voxels x CK channels) is staged global -> VGPR -> LDS while the
+//    previous chunk is being multiplied (register prefetch, one LDS buffer, two
+//    workgroups per CU overlap each other's barriers);
+//  * LDS image is [z][y][q][x] in 16-B elements (q = 4-channel group): the 64
+//    lanes of an A-fragment read touch consecutive 16-B slots -> conflict-free
+//    ds_read_b128 with compile-time offsets for every tap; stride-2 convolutions
+//    de-interleave even/odd x so their reads stay unit-stride;
+//  * weights are pre-packed once per layer into MFMA B-fragment order
+//    [cin/8][tap][cout/32][lane][4] and streamed from L2 with 16 B per lane,
+//    three fragments ahead of their use;
+//  * epilogue: y = acc*scale[co] + shift[co] (+ skip) (ReLU), 128 B per voxel.
+//
+// K order inside an 8-channel group: MFMA step j multiplies channels
+// {8g + j (lanes 0-31), 8g + 4 + j (lanes 32-63)}; A and B fragments agree on it.
+#include "common.hpp"
+
+namespace {
+
+constexpr int NTHREADS = 256;
+
+template <int S> struct Geo {
+  // input-tile extents for an output tile of TY rows x 32 columns, one z
+  static constexpr int IZ = 3;
+  static __host__ __device__ constexpr int IY(int TY) { return (TY - 1) * S + 3; }
+  static constexpr int IX = 31 * S + 3;                 // 34 or 65
+  static constexpr int XE = (IX + 1) / 2;               // even columns when S == 2
+  static constexpr int XP = (S == 1) ? IX : 2 * XE;     // LDS row pitch in 16-B elements
+  static __host__ __device__ constexpr int xmap(int x) {
+    return S == 1 ? x : ((x & 1) * XE + (x >> 1));
+  }
+};
+
+struct ConvParams {
+  const float* x; const float* w; const float* scale; const float* shift;
+  const float* res; float* y;
+  int B, Cin, Cout;
+  int Di, Hi, Wi, Do, Ho, Wo, Dr, Hr, Wr;
+  int relu;
+  int ntx, nty, ntiles;       // tile grid: x tiles, y tiles, total = B*Do*nty*ntx (x8 classes for deconv)
+};
+
+// XCD-aware persistent tile order: workgroups are dealt round-robin over the 8
+// XCDs, so worker (xcd = id % 8, slot = id / 8) walks a contiguous eighth of the
+// tile space -- neighbouring tiles (shared halos) meet in one XCD's L2.  Speed only.
+__device__ __forceinline__ int first_tile(int ntiles, int& step, int& end) {
+  const int id = blockIdx.x, G = gridDim.x;
+  if ((G & 7) != 0 || ntiles < 64) { step = G; end = ntiles; return id; }
+  const int xcd = id & 7, slot = id >> 3;
+  const int per = (ntiles + 7) >> 3;
+  const int lo = xcd * per;
+  end = min(ntiles, lo + per);
+  step = G >> 3;
+  return lo + slot;
+}
+
+// ----------------------------------------------------------------------------
+// Conv3d(k=3, padding=1, stride=S), Cout = 32*NT, Cin = multiple of CK.
+// ----------------------------------------------------------------------------
+template <int S, int NT, int TM, int CK>
+__global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) {
+  using G = Geo<S>;
+  constexpr int TY = 4 * TM;
+  constexpr int IY = G::IY(TY), IX = G::IX, XP = G::XP, IZ = G::IZ;
+  constexpr int NQ = CK / 4;                    // 16-B slots per voxel per chunk
+  constexpr int NG = CK / 8;                    // 8-channel MFMA groups per chunk
+  constexpr int NE = IZ * IY * IX * NQ;         // staged 16-B elements per chunk
+  constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
+  constexpr int ROW = NQ * XP;                  // elements per (z, y) row
+  extern __shared__ __attribute__((aligned(16))) f32x4 tile[];   // [IZ][IY][NQ][XP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nch = p.Cin / CK;
+  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(p.w);
+
+  int step, end;
+  int t = first_tile(p.ntiles, step, end);
+  if (t >= end) return;
+
+  // ---- staging: decode tile id, issue the global loads of one chunk ----------
+  f32x4 pf[NPF];
+  int tb, tz, ty0, tx0;
+  auto decode = [&](int id) {
+    tx0 = (id % p.ntx) * 32; id /= p.ntx;
+    ty0 = (id % p.nty) * TY; id /= p.nty;
+    tz = id % p.Do; tb = id / p.Do;
+  };
+  auto prefetch = [&](int id, int ck) {
+    int xb = (id % p.ntx) * 32 * S - 1; id /= p.ntx;
+    int yb = (id % p.nty) * TY * S - 1; id /= p.nty;
+    int zb = (id % p.Do) * S - 1; const int b = id / p.Do;
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      const int e = tid + k * NTHREADS;
+      const int q = e % NQ, v = e / NQ;
+      const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
+      const int zi = zb + zz, yi = yb + yy, xi = xb + xx;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (e < NE && zi >= 0 && zi < p.Di && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi)
+        val = *reinterpret_cast<const f32x4*>(
+            p.x + ((((long)b * p.Di + zi) * p.Hi + yi) * p.Wi + xi) * p.Cin + ck * CK + q * 4);
+      pf[k] = val;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      const int e = tid + k * NTHREADS;
+      const int q = e % NQ, v = e / NQ;
+      const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
+      if (e < NE) tile[(zz * IY + yy) * ROW + q * XP + G::xmap(xx)] = pf[k];
+    }
+  };
+
+  f32x16 acc[TM][NT];
+  const int lane_el = h * XP + r;               // this lane's slot within a (z,y) row
+  int ck = 0;
+  prefetch(t, 0);
+  while (true) {
+    __syncthreads();                            // every wave is done with the old chunk
+    commit();
+    __syncthreads();
+    // next (tile, chunk) item -> registers; lands while this chunk is multiplied
+    int nt_ = t, nck = ck + 1;
+    if (nck == nch) { nck = 0; nt_ = t + step; }
+    if (nt_ < end) prefetch(nt_, nck);
+
+    if (ck == 0) {
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    }
+    // ---- multiply: 27 taps x NG groups, B fragments three items ahead ----------
+    constexpr int NITEM = 27 * NG;
+    constexpr int AHEAD = 3;
+    f32x4 bq[AHEAD][NT];
+    const f32x4* wbase = wp + (long)ck * NG * 27 * NT * 64 + lane;   // [g][tap][nt][lane]
+    auto bload = [&](int item, f32x4 (&dst)[NT]) {
+      const int tap = item / NG, gi = item % NG;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) dst[n] = wbase[((gi * 27 + tap) * NT + n) * 64];
+    };
+#pragma unroll
+    for (int i = 0; i < AHEAD - 1; ++i) bload(i, bq[i]);
+#pragma unroll
+    for (int item = 0; item < NITEM; ++item) {
+      if (item + AHEAD - 1 < NITEM) bload(item + AHEAD - 1, bq[(item + AHEAD - 1) % AHEAD]);
+      const int tap = item / NG, gi = item % NG;
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      const int xoff = (S == 1) ? dx : ((dx & 1) * G::XE + (dx >> 1));
+      f32x4 a[TM];
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        const int yy = (wave * TM + m) * S + dy;
+        a[m] = tile[(dz * IY + yy) * ROW + (2 * gi) * XP + xoff + lane_el];
+      }
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const f32x4 bb = bq[item % AHEAD][n];
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, bb.x, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, bb.y, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bb.z, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bb.w, acc[m][n], 0, 0, 0);
+        }
+    }
+    // ---- epilogue after the last chunk of a tile --------------------------------
+    if (ck == nch - 1) {
+      decode(t);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int co = n * 32 + r;
+        const float sc = p.scale ? p.scale[co] : 1.f;
+        const float sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+          const int yo = ty0 + wave * TM + m;
+          if (yo >= p.Ho) continue;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int xo = tx0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (xo >= p.Wo) continue;
+            float v = acc[m][n][i] * sc + sh;
+            if (p.res)
+              v += p.res[((((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo) * p.Cout + co];
+            if (p.relu) v = fmaxf(v, 0.f);
+            p.y[((((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo) * p.Cout + co] = v;
+          }
+        }
+      }
+    }
+    ck = nck; t = nt_;
+    if (t >= end) break;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1), Cout = 32*NT.
+//   out[o] += in[i] * w[k],  o = 2i - 1 + k   per dimension, so an output of parity
+//   0 (o = 2m) has one tap (k=1, i=m) and of parity 1 (o = 2m+1) two taps
+//   (k=2, i=m) and (k=0, i=m+1).  A work item is (input-grid tile, parity class):
+//   a dense little convolution with 1..8 taps on the input grid.
+// ----------------------------------------------------------------------------
+template <int NT, int TM, int CK>
+__global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p) {
+  constexpr int TY = 4 * TM;
+  constexpr int IZ = 2, IY = TY + 1, IX = 33, XP = 34;
+  constexpr int NQ = CK / 4, NG = CK / 8;
+  constexpr int NE = IZ * IY * IX * NQ;
+  constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
+  constexpr int ROW = NQ * XP;
+  extern __shared__ __attribute__((aligned(16))) f32x4 tile[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nch = p.Cin / CK;
+  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(p.w);
+  const int lane_el = h * XP + r;
+
+  for (int item = blockIdx.x; item < p.ntiles; item += gridDim.x) {
+    const int cls = item & 7;
+    int id = item >> 3;
+    const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
+    const int ty0 = (id % p.nty) * TY; id /= p.nty;
+    const int tz = id % p.Di; const int tb = id / p.Di;
+    const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    const int zo = 2 * tz + pz;
+    if (zo >= p.Do) continue;                       // cropped away (uniform per workgroup)
+
+    f32x16 acc[TM][NT];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+    for (int ck = 0; ck < nch; ++ck) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NPF; ++k) {
+        const int e = tid + k * NTHREADS;
+        const int q = e % NQ, v = e / NQ;
+        const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
+        const int zi = tz + zz, yi = ty0 + yy, xi = tx0 + xx;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (e < NE && zi < p.Di && yi < p.Hi && xi < p.Wi)
+          val = *reinterpret_cast<const f32x4*>(
+              p.x + ((((long)tb * p.Di + zi) * p.Hi + yi) * p.Wi + xi) * p.Cin + ck * CK + q * 4);
+        if (e < NE) tile[(zz * IY + yy) * ROW + q * XP + xx] = val;
+      }
+      __syncthreads();
+      for (int iz = 0; iz <= pz; ++iz)
+        for (int iy = 0; iy <= py; ++iy)
+          for (int ix = 0; ix <= px; ++ix) {
+            // parity 0: (k=1, di=0); parity 1: first (k=2, di=0) then (k=0, di=1)
+            const int kz = pz ? (iz ? 0 : 2) : 1, ky = py ? (iy ? 0 : 2) : 1,
+                      kx = px ? (ix ? 0 : 2) : 1;
+            const int tap = (kz * 3 + ky) * 3 + kx;
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+              f32x4 bb[NT];
+#pragma unroll
+              for (int n = 0; n < NT; ++n)
+                bb[n] = wp[((((long)(ck * NG + gi)) * 27 + tap) * NT + n) * 64 + lane];
+#pragma unroll
+              for (int m = 0; m < TM; ++m) {
+                const int yy = wave * TM + m + iy;
+                const f32x4 a = tile[(iz * IY + yy) * ROW + (2 * gi) * XP + ix + lane_el];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb[n].x, acc[m][n], 0, 0, 0);
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb[n].y, acc[m][n], 0, 0, 0);
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bb[n].z, acc[m][n], 0, 0, 0);
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bb[n].w, acc[m][n], 0, 0, 0);
+                }
+              }
+            }
+          }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = n * 32 + r;
+      const float sc = p.scale ? p.scale[co] : 1.f;
+      const float sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        const int yo = 2 * (ty0 + wave * TM + m) + py;
+        if (ty0 + wave * TM + m >= p.Hi || yo >= p.Ho) continue;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int xm = tx0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int xo = 2 * xm + px;
+          if (xm >= p.Wi || xo >= p.Wo) continue;
+          float v = acc[m][n][i] * sc + sh;
+          if (p.res)
+            v += p.res[((((long)tb * p.Dr + zo) * p.Hr + yo) * p.Wr + xo) * p.Cout + co];
+          if (p.relu) v = fmaxf(v, 0.f);
+          p.y[((((long)tb * p.Do + zo) * p.Ho + yo) * p.Wo + xo) * p.Cout + co] = v;
+        }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// Cout = 1 (PSMNet classif heads 32->1, GCNet l37): a 27*Cin-long dot product
+// per voxel.  An MFMA tile would waste 31/32 of its columns, so this is a VALU
+// kernel on the same LDS image: one thread per output voxel, weights read through
+// the scalar cache (wave-uniform addresses).
+// Weights packed as [tap][Cin].
+// ----------------------------------------------------------------------------
+template <int CK>
+__global__ __launch_bounds__(NTHREADS) void conv3d_cout1_kernel(ConvParams p) {
+  constexpr int TY = 8;
+  constexpr int IY = TY + 2, IX = 34, XP = 34, IZ = 3;
+  constexpr int NQ = CK / 4;
+  constexpr int NE = IZ * IY * IX * NQ;
+  constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
+  constexpr int ROW = NQ * XP;
+  extern __shared__ __attribute__((aligned(16))) f32x4 tile[];
+  const int tid = threadIdx.x;
+  const int r = tid & 31, ty = tid >> 5;
+  const int nch = p.Cin / CK;
+  for (int item = blockIdx.x; item < p.ntiles; item += gridDim.x) {
+    int id = item;
+    const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
+    const int ty0 = (id % p.nty) * TY; id /= p.nty;
+    const int tz = id % p.Do; const int tb = id / p.Do;
+    float acc = 0.f;
+    for (int ck = 0; ck < nch; ++ck) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NPF; ++k) {
+        const int e = tid + k * NTHREADS;
+        const int q = e % NQ, v = e / NQ;
+        const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
+        const int zi = tz - 1 + zz, yi = ty0 - 1 + yy, xi = tx0 - 1 + xx;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (e < NE && zi >= 0 && zi < p.Di && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi)
+          val = *reinterpret_cast<const f32x4*>(
+              p.x + ((((long)tb * p.Di + zi) * p.Hi + yi) * p.Wi + xi) * p.Cin + ck * CK + q * 4);
+        if (e < NE) tile[(zz * IY + yy) * ROW + q * XP + xx] = val;
+      }
+      __syncthreads();
+      const float* wc = p.w + ck * CK;
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const f32x4 a = tile[(dz * IY + ty + dy) * ROW + q * XP + r + dx];
+          const float* w4 = wc + (long)tap * p.Cin + q * 4;
+          acc = fmaf(a.x, w4[0], acc); acc = fmaf(a.y, w4[1], acc);
+          acc = fmaf(a.z, w4[2], acc); acc = fmaf(a.w, w4[3], acc);
+        }
+      }
+    }
+    const int yo = ty0 + ty, xo = tx0 + r;
+    if (yo < p.Ho && xo < p.Wo) {
+      float v = acc * (p.scale ? p.scale[0] : 1.f) + (p.shift ? p.shift[0] : 0.f);
+      if (p.res) v += p.res[(((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo];
+      if (p.relu) v = fmaxf(v, 0.f);
+      p.y[(((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo] = v;
+    }
+  }
+}
+
+// ConvTranspose3d(k3,s2,p1,op1) to one channel (GCNet l37, models/gcnet.py:63,100):
+// thread per output voxel, gathers its 1..8 input voxels straight from L2.
+__global__ __launch_bounds__(NTHREADS) void deconv3d_cout1_kernel(ConvParams p) {
+  const int xo = blockIdx.x * NTHREADS + threadIdx.x;
+  const int yo = blockIdx.y;
+  const int zo = blockIdx.z % p.Do, b = blockIdx.z / p.Do;
+  if (xo >= p.Wo) return;
+  float acc = 0.f;
+  const int pz = zo & 1, py = yo & 1, px = xo & 1;
+  const int mz = zo >> 1, my = yo >> 1, mx = xo >> 1;
+  for (int iz = 0; iz <= pz; ++iz) {
+    const int zi = mz + iz, kz = pz ? (iz ? 0 : 2) : 1;
+    if (zi >= p.Di) continue;
+    for (int iy = 0; iy <= py; ++iy) {
+      const int yi = my + iy, ky = py ? (iy ? 0 : 2) : 1;
+      if (yi >= p.Hi) continue;
+      for (int ix = 0; ix <= px; ++ix) {
+        const int xi = mx + ix, kx = px ? (ix ? 0 : 2) : 1;
+        if (xi >= p.Wi) continue;
+        const int tap = (kz * 3 + ky) * 3 + kx;
+        const f32x4* a = reinterpret_cast<const f32x4*>(
+            p.x + ((((long)b * p.Di + zi) * p.Hi + yi) * p.Wi + xi) * p.Cin);
+        const f32x4* w = reinterpret_cast<const f32x4*>(p.w + (long)tap * p.Cin);
+        for (int c = 0; c < p.Cin / 4; ++c) {
+          const f32x4 av = a[c], wv = w[c];
+          acc = fmaf(av.x, wv.x, acc); acc = fmaf(av.y, wv.y, acc);
+          acc = fmaf(av.z, wv.z, acc); acc = fmaf(av.w, wv.w, acc);
+        }
+      }
+    }
+  }
+  float v = acc * (p.scale ? p.scale[0] : 1.f) + (p.shift ? p.shift[0] : 0.f);
+  if (p.res) v += p.res[(((long)b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo];
+  if (p.relu) v = fmaxf(v, 0.f);
+  p.y[(((long)b * p.Do + zo) * p.Ho + yo) * p.Wo + xo] = v;
+}
+
+// ----------------------------------------------------------------------------
+// Weight packing (once per layer): torch layout -> MFMA B-fragment order.
+// ----------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin,
+                                    int Cout, int transposed) {
+  const long n = (long)Cin * Cout * 27;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  int cin, cout, tap;
+  if (Cout == 1) {                       // [tap][cin]
+    cin = idx % Cin; tap = idx / Cin; cout = 0;
+  } else {                               // [cin/8][tap][cout/32][lane][4]
+    const int NT = Cout / 32;
+    long i = idx;
+    const int j = i & 3; i >>= 2;
+    const int lane = i & 63; i >>= 6;
+    const int n_ = i % NT; i /= NT;
+    tap = i % 27; const int g = i / 27;
+    cin = 8 * g + 4 * (lane >> 5) + j;
+    cout = 32 * n_ + (lane & 31);
+  }
+  const long src = transposed ? (((long)cin * Cout + cout) * 27 + tap)
+                              : (((long)cout * Cin + cin) * 27 + tap);
+  out[idx] = w[src];
+}
+
+template <typename K>
+int launch_tiles(K kernel, const ConvParams& p, size_t lds, hipStream_t s, int max_blocks) {
+  if (lds > 64 * 1024) {
+    static thread_local const void* configured[16];
+    static thread_local int nconf = 0;
+    bool seen = false;
+    for (int i = 0; i < nconf; ++i) seen |= (configured[i] == (const void*)kernel);
+    if (!seen) {
+      if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess)
+        return DSM_ERR_LAUNCH;
+      if (nconf < 16) configured[nconf++] = (const void*)kernel;
+    }
+  }
+  int blocks = p.ntiles < max_blocks ? p.ntiles : max_blocks;
+  if (blocks >= 8) blocks &= ~7;                 // whole rounds over the 8 XCDs
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(NTHREADS), lds, s, p);
+  return dsm_launch_status();
+}
+
+template <int S, int NT, int TM, int CK>
+int run_conv(ConvParams p, hipStream_t s) {
+  constexpr int TY = 4 * TM;
+  p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, TY);
+  const long nt = (long)p.B * p.Do * p.nty * p.ntx;
+  if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
+  p.ntiles = (int)nt;
+  const size_t lds = (size_t)3 * Geo<S>::IY(TY) * (CK / 4) * Geo<S>::XP * 16;
+  return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK>, p, lds, s, 512);
+}
+
+template <int NT, int TM, int CK>
+int run_deconv(ConvParams p, hipStream_t s) {
+  constexpr int TY = 4 * TM;
+  p.ntx = dsm_cdiv(p.Wi, 32); p.nty = dsm_cdiv(p.Hi, TY);
+  const long nt = (long)p.B * p.Di * p.nty * p.ntx * 8;
+  if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
+  p.ntiles = (int)nt;
+  const size_t lds = (size_t)2 * (TY + 1) * (CK / 4) * 34 * 16;
+  return launch_tiles(deconv3d_mfma_kernel<NT, TM, CK>, p, lds, s, 512);
+}
+
+}  // namespace
+
+extern "C" size_t dsm_conv3d_packed_weight_bytes(int Cin, int Cout, int transposed) {
+  (void)transposed;
+  if (Cin <= 0 || Cout <= 0) return 0;
+  return (size_t)Cin * Cout * 27 * sizeof(float);
+}
+
+extern "C" int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed, int Cin, int Cout,
+                                       int transposed, dsm_stream_t stream) {
+  DSM_REQUIRE(w_torch && w_packed && w_torch != w_packed, DSM_ERR_ARG);
+  DSM_REQUIRE(Cin > 0 && Cout > 0, DSM_ERR_ARG);
+  DSM_REQUIRE(Cin % 8 == 0 && (Cout == 1 || Cout % 32 == 0), DSM_ERR_UNSUPPORTED);
+  const long n = (long)Cin * Cout * 27;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const float*)w_torch, (float*)w_packed, Cin, Cout,
+                     transposed);
+  return dsm_launch_status();
+}
+
+extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
+  DSM_REQUIRE(a && a->x && a->w_packed && a->y, DSM_ERR_ARG);
+  DSM_REQUIRE(a->B > 0 && a->Cin > 0 && a->Cout > 0, DSM_ERR_ARG);
+  DSM_REQUIRE(a->Di > 0 && a->Hi > 0 && a->Wi > 0 && a->Do > 0 && a->Ho > 0 && a->Wo > 0,
+              DSM_ERR_ARG);
+  DSM_REQUIRE(a->stride == 1 || a->stride == 2, DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(!a->transposed || a->stride == 2, DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(a->Cin % 16 == 0, DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(dsm_aligned16(a->x) && dsm_aligned16(a->w_packed) && dsm_aligned16(a->y),
+              DSM_ERR_ALIGN);
+  // natural output size; the caller may ask for a smaller corner (crop-add), never more
+  const int nD = a->transposed ? 2 * a->Di : (a->Di - 1) / a->stride + 1;
+  const int nH = a->transposed ? 2 * a->Hi : (a->Hi - 1) / a->stride + 1;
+  const int nW = a->transposed ? 2 * a->Wi : (a->Wi - 1) / a->stride + 1;
+  DSM_REQUIRE(a->Do <= nD && a->Ho <= nH && a->Wo <= nW, DSM_ERR_ARG);
+  if (a->residual)
+    DSM_REQUIRE(a->Dr >= a->Do && a->Hr >= a->Ho && a->Wr >= a->Wo, DSM_ERR_ARG);
+  ConvParams p;
+  p.x = (const float*)a->x; p.w = (const float*)a->w_packed; p.scale = a->scale;
+  p.shift = a->shift; p.res = (const float*)a->residual; p.y = (float*)a->y;
+  p.B = a->B; p.Cin = a->Cin; p.Cout = a->Cout;
+  p.Di = a->Di; p.Hi = a->Hi; p.Wi = a->Wi; p.Do = a->Do; p.Ho = a->Ho; p.Wo = a->Wo;
+  p.Dr = a->Dr; p.Hr = a->Hr; p.Wr = a->Wr; p.relu = a->relu;
+  p.ntx = p.nty = p.ntiles = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->Cout == 1) {
+    if (a->transposed) {
+      DSM_REQUIRE(a->Ho <= 65535 && (long)a->B * a->Do <= 65535, DSM_ERR_UNSUPPORTED);
+      dim3 grid(dsm_cdiv(a->Wo, NTHREADS), a->Ho, a->B * a->Do);
+      hipLaunchKernelGGL(deconv3d_cout1_kernel, grid, dim3(NTHREADS), 0, s, p);
+      return dsm_launch_status();
+    }
+    DSM_REQUIRE(a->stride == 1, DSM_ERR_UNSUPPORTED);
+    p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, 8);
+    p.ntiles = p.B * p.Do * p.nty * p.ntx;
+    const size_t lds = (size_t)3 * 10 * 4 * 34 * 16;
+    return launch_tiles(conv3d_cout1_kernel<16>, p, lds, s, 2048);
+  }
+  DSM_REQUIRE(a->Cout == 32 || a->Cout == 64 || a->Cout == 128, DSM_ERR_UNSUPPORTED);
+  // Tile height: 8 rows (TM = 2) when that still gives every CU two workgroups of
+  // work, else 4 rows.  Stride 2 stages 8 channels per chunk to fit two workgroups.
+  if (a->transposed) {
+    const bool big = (long)a->B * a->Di * dsm_cdiv(a->Hi, 8) * dsm_cdiv(a->Wi, 32) * 8 >= 1024;
+    switch (a->Cout) {
+      case 32:  return big ? run_deconv<1, 2, 16>(p, s) : run_deconv<1, 1, 16>(p, s);
+      case 64:  return big ? run_deconv<2, 2, 16>(p, s) : run_deconv<2, 1, 16>(p, s);
+      default:  return run_deconv<4, 1, 16>(p, s);
+    }
+  }
+  const bool big = (long)a->B * a->Do * dsm_cdiv(a->Ho, 8) * dsm_cdiv(a->Wo, 32) >= 1024;
+  if (a->stride == 1) {
+    switch (a->Cout) {
+      case 32:  return big ? run_conv<1, 1, 2, 16>(p, s) : run_conv<1, 1, 1, 16>(p, s);
+      case 64:  return big ? run_conv<1, 2, 2, 8>(p, s) : run_conv<1, 2, 1, 16>(p, s);
+      default:  return run_conv<1, 4, 1, 16>(p, s);
+    }
+  }
+  switch (a->Cout) {
+    case 32:  return run_conv<2, 1, 1, 8>(p, s);
+    case 64:  return run_conv<2, 2, 1, 8>(p, s);
+    default:  return run_conv<2, 4, 1, 8>(p, s);
+  }
+}

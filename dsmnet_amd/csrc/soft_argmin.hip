@@ -1,0 +1,279 @@
+// Fused soft-argmin disparity regression for gfx950.
+//
+// Replaces, per head, F.upsample(trilinear) -> F.softmax -> permute -> matmul(arange)
+// (models/psmnet/stackhourglass.py:152-166, submodule.py:56-63) and
+// Softmax2d(-x) -> permute -> matmul (models/gcnet.py:104-111): four-plus passes
+// over a (B,D,H,W) tensor become one kernel that interpolates on the fly, keeps an
+// online softmax in registers and writes only the (B,H,W) disparity.
+//
+// Lane layout: a wave covers 64/DSPLIT consecutive x of one row times DSPLIT
+// disparity segments; the DSPLIT partial (max, sum, weighted sum) triples of a
+// pixel are merged with wave shuffles (__shfl_xor), no LDS.  Lanes along x keep
+// the (B,D,H,W) reads of the GCNet form coalesced.
+//
+// Algorithmic bytes: fused PSMNet head 384x1280 = 5.90 MB
+// cost read + 1.97 MB disparity written; GCNet 256x512 = 100.7 MB read + 0.5 MB.
+#include "common.hpp"
+
+struct Lerp { int i0, i1; float w0, w1; };
+
+// torch's area_pixel_compute_source_index + guard_index_and_lambda
+// (aten/src/ATen/native/UpSample.h), which is what F.upsample/F.interpolate run.
+__device__ __forceinline__ Lerp lerp_at(int o, float scale, int in_size, int out_size,
+                                        int align) {
+  Lerp r;
+  if (in_size == out_size) { r.i0 = r.i1 = o; r.w0 = 1.f; r.w1 = 0.f; return r; }
+  float src = align ? scale * (float)o : fmaxf(scale * ((float)o + 0.5f) - 0.5f, 0.f);
+  int i0 = min((int)floorf(src), in_size - 1);
+  r.i0 = i0;
+  r.i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  r.w1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+  r.w0 = 1.f - r.w1;
+  return r;
+}
+
+struct Sm { float m, l, s; };   // running max, sum exp, sum d*exp
+
+__device__ __forceinline__ void sm_push(Sm& a, float v, float d) {
+  if (v > a.m) {                       // rare after the first few bins
+    const float r = __expf(a.m - v);   // exp(-inf) = 0 on the first bin
+    a.l *= r; a.s *= r; a.m = v;
+  }
+  const float e = __expf(v - a.m);
+  a.l += e;
+  a.s = fmaf(d, e, a.s);
+}
+
+__device__ __forceinline__ Sm sm_merge(const Sm& a, const Sm& b) {
+  Sm o;
+  o.m = fmaxf(a.m, b.m);
+  const float ra = (a.m == -INFINITY) ? 0.f : __expf(a.m - o.m);
+  const float rb = (b.m == -INFINITY) ? 0.f : __expf(b.m - o.m);
+  o.l = a.l * ra + b.l * rb;
+  o.s = a.s * ra + b.s * rb;
+  return o;
+}
+
+struct SaParams {
+  const float* cost; float* disp; float* stats;
+  int Dc, Hc, Wc, D, H, W;
+  float sd, sh, sw;      // source-index scales (torch: in/out, or (in-1)/(out-1))
+  float sign;            // +1 (PSMNet) / -1 (GCNet)
+  int align;
+};
+
+// bilinear sample of coarse plane k at the pixel's (y, x) stencil
+struct Stencil { int o00, o01, o10, o11; float wy0, wy1, wx0, wx1; };
+__device__ __forceinline__ float plane_at(const float* __restrict__ base, long plane_stride, int k,
+                                          const Stencil& st) {
+  const float* p = base + (long)k * plane_stride;
+  return st.wy0 * (st.wx0 * p[st.o00] + st.wx1 * p[st.o01]) +
+         st.wy1 * (st.wx0 * p[st.o10] + st.wx1 * p[st.o11]);
+}
+
+template <bool UPSAMPLE, int DSPLIT>
+__global__ __launch_bounds__(256) void soft_argmin_fwd_kernel(SaParams p) {
+  constexpr int PXW = DSM_WAVE / DSPLIT;          // pixels per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg = lane / PXW;
+  const int x = (blockIdx.x * 4 + wave) * PXW + (lane % PXW);
+  const int y = blockIdx.y, b = blockIdx.z;
+  const bool live = x < p.W;
+  const int dper = (p.D + DSPLIT - 1) / DSPLIT;
+  const int d_lo = seg * dper, d_hi = min(p.D, d_lo + dper);
+  Sm acc = {-INFINITY, 0.f, 0.f};
+  if (live) {
+    if (UPSAMPLE) {
+      const Lerp ly = lerp_at(y, p.sh, p.Hc, p.H, p.align);
+      const Lerp lx = lerp_at(x, p.sw, p.Wc, p.W, p.align);
+      Stencil st;
+      st.o00 = ly.i0 * p.Wc + lx.i0; st.o01 = ly.i0 * p.Wc + lx.i1;
+      st.o10 = ly.i1 * p.Wc + lx.i0; st.o11 = ly.i1 * p.Wc + lx.i1;
+      st.wy0 = ly.w0; st.wy1 = ly.w1; st.wx0 = lx.w0; st.wx1 = lx.w1;
+      const long ps = (long)p.Hc * p.Wc;
+      const float* base = p.cost + (long)b * p.Dc * ps;
+      int k = -2; float P0 = 0.f, P1 = 0.f;          // planes k and min(k+1, Dc-1)
+      for (int d = d_lo; d < d_hi; ++d) {
+        const Lerp ld = lerp_at(d, p.sd, p.Dc, p.D, p.align);
+        if (ld.i0 != k) {
+          if (ld.i0 == k + 1) { P0 = P1; }
+          else { P0 = plane_at(base, ps, ld.i0, st); }
+          k = ld.i0;
+          P1 = plane_at(base, ps, min(k + 1, p.Dc - 1), st);
+        }
+        const float v = ld.w0 * P0 + ld.w1 * (ld.i1 == k ? P0 : P1);
+        sm_push(acc, p.sign * v, (float)d);
+      }
+    } else {
+      const long ps = (long)p.H * p.W;
+      const float* src = p.cost + (long)b * p.D * ps + (long)y * p.W + x;
+#pragma unroll 4
+      for (int d = d_lo; d < d_hi; ++d) sm_push(acc, p.sign * src[d * ps], (float)d);
+    }
+  }
+#pragma unroll
+  for (int off = PXW; off < DSM_WAVE; off <<= 1) {
+    Sm o;
+    o.m = __shfl_xor(acc.m, off); o.l = __shfl_xor(acc.l, off); o.s = __shfl_xor(acc.s, off);
+    acc = sm_merge(acc, o);
+  }
+  if (live && seg == 0) {
+    const long o = ((long)b * p.H + y) * p.W + x;
+    p.disp[o] = acc.s / acc.l;
+    if (p.stats) {
+      const long hw = (long)p.H * p.W;
+      p.stats[(long)b * 2 * hw + (long)y * p.W + x] = acc.m;
+      p.stats[(long)b * 2 * hw + hw + (long)y * p.W + x] = acc.l;
+    }
+  }
+}
+
+// Backward: dcost_fine[d] = sign * p_d * (d - E) * g, then (PSMNet form) the adjoint
+// of the trilinear stencil.  One thread per full-resolution pixel walks d; the
+// contributions to a coarse plane are summed in registers and leave as 4 float
+// atomics per (pixel, coarse plane).
+struct SaBwdParams {
+  const float* cost; const float* disp; const float* stats; const float* gdisp; float* dcost;
+  int Dc, Hc, Wc, D, H, W;
+  float sd, sh, sw, sign;
+  int align;
+};
+
+__device__ __forceinline__ void scatter4(float* base, long ps, int k, const Stencil& st, float a) {
+  float* q = base + (long)k * ps;
+  atomicAdd(q + st.o00, a * st.wy0 * st.wx0);
+  atomicAdd(q + st.o01, a * st.wy0 * st.wx1);
+  atomicAdd(q + st.o10, a * st.wy1 * st.wx0);
+  atomicAdd(q + st.o11, a * st.wy1 * st.wx1);
+}
+
+template <bool UPSAMPLE>
+__global__ __launch_bounds__(256) void soft_argmin_bwd_kernel(SaBwdParams p) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x >= p.W) return;
+  const long hw = (long)p.H * p.W;
+  const long o = (long)y * p.W + x;
+  const float m = p.stats[(long)b * 2 * hw + o];
+  const float inv_l = 1.f / p.stats[(long)b * 2 * hw + hw + o];
+  const float E = p.disp[(long)b * hw + o];
+  const float g = p.gdisp[(long)b * hw + o] * p.sign;
+  if (UPSAMPLE) {
+    const Lerp ly = lerp_at(y, p.sh, p.Hc, p.H, p.align);
+    const Lerp lx = lerp_at(x, p.sw, p.Wc, p.W, p.align);
+    Stencil st;
+    st.o00 = ly.i0 * p.Wc + lx.i0; st.o01 = ly.i0 * p.Wc + lx.i1;
+    st.o10 = ly.i1 * p.Wc + lx.i0; st.o11 = ly.i1 * p.Wc + lx.i1;
+    st.wy0 = ly.w0; st.wy1 = ly.w1; st.wx0 = lx.w0; st.wx1 = lx.w1;
+    const long ps = (long)p.Hc * p.Wc;
+    const float* base = p.cost + (long)b * p.Dc * ps;
+    float* gbase = p.dcost + (long)b * p.Dc * ps;
+    int k = -2; float P0 = 0.f, P1 = 0.f, A0 = 0.f, A1 = 0.f;
+    for (int d = 0; d < p.D; ++d) {
+      const Lerp ld = lerp_at(d, p.sd, p.Dc, p.D, p.align);
+      if (ld.i0 != k) {
+        if (k >= 0) {
+          scatter4(gbase, ps, k, st, A0);
+          if (ld.i0 != k + 1 && k + 1 < p.Dc) scatter4(gbase, ps, k + 1, st, A1);
+        }
+        if (ld.i0 == k + 1) { P0 = P1; A0 = A1; }
+        else { P0 = plane_at(base, ps, ld.i0, st); A0 = 0.f; }
+        k = ld.i0; A1 = 0.f;
+        P1 = plane_at(base, ps, min(k + 1, p.Dc - 1), st);
+      }
+      const bool same = (ld.i1 == k);
+      const float v = p.sign * (ld.w0 * P0 + ld.w1 * (same ? P0 : P1));
+      const float gf = __expf(v - m) * inv_l * ((float)d - E) * g;
+      A0 = fmaf(gf, same ? 1.f : ld.w0, A0);
+      if (!same) A1 = fmaf(gf, ld.w1, A1);
+    }
+    if (k >= 0) {
+      scatter4(gbase, ps, k, st, A0);
+      if (k + 1 < p.Dc) scatter4(gbase, ps, k + 1, st, A1);
+    }
+  } else {
+    const float* src = p.cost + (long)b * p.D * hw + o;
+    float* dst = p.dcost + (long)b * p.D * hw + o;
+#pragma unroll 4
+    for (int d = 0; d < p.D; ++d) {
+      const float v = p.sign * src[d * hw];
+      dst[d * hw] = __expf(v - m) * inv_l * ((float)d - E) * g;
+    }
+  }
+}
+
+static float src_scale(int in, int out, int align) {
+  if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  return (float)in / (float)out;
+}
+
+static int check_sa(const void* cost, const void* disp, int B, int Dc, int Hc, int Wc, int D,
+                    int H, int W, int dtype) {
+  DSM_REQUIRE(cost && disp, DSM_ERR_ARG);
+  DSM_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && D > 0 && H > 0 && W > 0, DSM_ERR_ARG);
+  DSM_REQUIRE(dtype == DSM_F32, DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(H <= 65535 && B <= 65535, DSM_ERR_UNSUPPORTED);
+  return DSM_OK;
+}
+
+// DSPLIT can be forced for A/B measurements (profiles/): DSM_SOFTARGMIN_DSPLIT=1|2|4
+static int pick_dsplit(int D) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("DSM_SOFTARGMIN_DSPLIT");
+    forced = e ? atoi(e) : 0;
+  }
+  int ds = forced > 0 ? forced : 4;
+  while (ds > 1 && D < 2 * ds) ds >>= 1;
+  return (ds == 1 || ds == 2 || ds == 4) ? ds : 4;
+}
+
+extern "C" int dsm_soft_argmin_fwd(const void* cost, void* disp, void* stats, int B, int Dc,
+                                   int Hc, int Wc, int D, int H, int W, int negate,
+                                   int align_corners, int dtype, dsm_stream_t stream) {
+  int rc = check_sa(cost, disp, B, Dc, Hc, Wc, D, H, W, dtype);
+  if (rc != DSM_OK) return rc;
+  SaParams p;
+  p.cost = (const float*)cost; p.disp = (float*)disp; p.stats = (float*)stats;
+  p.Dc = Dc; p.Hc = Hc; p.Wc = Wc; p.D = D; p.H = H; p.W = W;
+  p.sd = src_scale(Dc, D, align_corners); p.sh = src_scale(Hc, H, align_corners);
+  p.sw = src_scale(Wc, W, align_corners);
+  p.sign = negate ? -1.f : 1.f; p.align = align_corners;
+  const bool up = !(Dc == D && Hc == H && Wc == W);
+  const int ds = pick_dsplit(D);
+  const int px_per_block = 4 * (DSM_WAVE / ds);
+  dim3 grid(dsm_cdiv(W, px_per_block), H, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define SA_LAUNCH(UP, DS) hipLaunchKernelGGL((soft_argmin_fwd_kernel<UP, DS>), grid, block, 0, s, p)
+  if (up) { if (ds == 4) SA_LAUNCH(true, 4); else if (ds == 2) SA_LAUNCH(true, 2); else SA_LAUNCH(true, 1); }
+  else    { if (ds == 4) SA_LAUNCH(false, 4); else if (ds == 2) SA_LAUNCH(false, 2); else SA_LAUNCH(false, 1); }
+#undef SA_LAUNCH
+  return dsm_launch_status();
+}
+
+extern "C" int dsm_soft_argmin_bwd(const void* cost, const void* disp, const void* stats,
+                                   const void* gdisp, void* dcost, int B, int Dc, int Hc, int Wc,
+                                   int D, int H, int W, int negate, int align_corners, int dtype,
+                                   dsm_stream_t stream) {
+  int rc = check_sa(cost, disp, B, Dc, Hc, Wc, D, H, W, dtype);
+  if (rc != DSM_OK) return rc;
+  DSM_REQUIRE(stats && gdisp && dcost, DSM_ERR_ARG);
+  SaBwdParams p;
+  p.cost = (const float*)cost; p.disp = (const float*)disp; p.stats = (const float*)stats;
+  p.gdisp = (const float*)gdisp; p.dcost = (float*)dcost;
+  p.Dc = Dc; p.Hc = Hc; p.Wc = Wc; p.D = D; p.H = H; p.W = W;
+  p.sd = src_scale(Dc, D, align_corners); p.sh = src_scale(Hc, H, align_corners);
+  p.sw = src_scale(Wc, W, align_corners);
+  p.sign = negate ? -1.f : 1.f; p.align = align_corners;
+  const bool up = !(Dc == D && Hc == H && Wc == W);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(dsm_cdiv(W, 256), H, B), block(256);
+  if (up) {
+    if (hipMemsetAsync(dcost, 0, (size_t)B * Dc * Hc * Wc * sizeof(float), s) != hipSuccess)
+      return DSM_ERR_LAUNCH;
+    hipLaunchKernelGGL(soft_argmin_bwd_kernel<true>, grid, block, 0, s, p);
+  } else {
+    hipLaunchKernelGGL(soft_argmin_bwd_kernel<false>, grid, block, 0, s, p);
+  }
+  return dsm_launch_status();
+}

@@ -1,0 +1,156 @@
+/*
+ * dsmnet_hip.h -- C ABI of the MI355X (gfx950) stereo cost-volume path.
+ *
+ * The reference (sunshinnnn/DSMnet) is pure Python: it defines NO plugin,
+ * operator or FFI interface for this path.  Each entry
+ * point below therefore cites the reference *Python code it replaces*; the
+ * binding a maintainer adds on the reference side is a ctypes stub
+ * (INTEGRATION.md, and dsmnet_amd/_lib.py is that stub in full).
+ *
+ * Conventions
+ *  - plain C: device pointers + sizes; no torch types, no C++ in the signatures;
+ *  - every buffer is caller-allocated device memory; the library never
+ *    allocates, frees, or synchronises; all work is enqueued on `stream`
+ *    (a hipStream_t passed as void*; NULL = the null stream);
+ *  - return value: DSM_OK (0) or a negative DSM_ERR_* code; no exceptions
+ *    cross the boundary; dsm_strerror() names a code;
+ *  - dtype: only DSM_F32 is implemented (the reference computes in fp32:
+ *    torch.FloatTensor, models/psmnet/stackhourglass.py:124);
+ *  - 4-D feature maps are NCHW contiguous, as torch hands them over;
+ *  - 5-D volumes are either DSM_NCDHW (torch contiguous) or DSM_NDHWC
+ *    (torch.channels_last_3d), selected per call.
+ */
+#ifndef DSMNET_HIP_H
+#define DSMNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSM_ABI_VERSION 1
+
+#define DSM_OK               0
+#define DSM_ERR_ARG         -1   /* null pointer, non-positive size, bad enum      */
+#define DSM_ERR_UNSUPPORTED -2   /* valid request this build has no kernel for     */
+#define DSM_ERR_LAUNCH      -3   /* HIP reported a launch failure                   */
+#define DSM_ERR_ALIGN       -4   /* a pointer is not aligned as the kernel needs    */
+
+enum dsm_dtype  { DSM_F32 = 0 };
+enum dsm_layout { DSM_NCDHW = 0, DSM_NDHWC = 1 };
+
+typedef void* dsm_stream_t;      /* hipStream_t */
+
+int         dsm_abi_version(void);
+const char* dsm_strerror(int code);
+
+/* ---------------------------------------------------------------------------
+ * (a1) 1-D correlation.  Replaces Corr1d.forward, models/util_conv.py:71-86
+ * (python loop over D slice-multiplies) and, for the gradient, autograd through it.
+ *   out[b,i,y,x] = sum_c fL[b,c,y,x] * fR[b,c,y,x - i*stride]   (x >= i*stride, i < W)
+ *   ksize > 1: every plane box-filtered, zero padding counted in the divisor
+ *   (nn.AvgPool2d(k, 1, k//2), util_conv.py:82-85).
+ * fL, fR: (B,C,H,W); out: (B,D,H,W); tmp: (B,D,H,W) scratch, needed iff ksize > 1.
+ * ------------------------------------------------------------------------- */
+int dsm_corr1d_fwd(const void* fL, const void* fR, void* out, void* tmp,
+                   int B, int C, int H, int W, int D, int stride, int ksize,
+                   int dtype, dsm_stream_t stream);
+
+/* grad_out: (B,D,H,W); dfL, dfR: (B,C,H,W), fully overwritten.
+ * tmp: (B,D,H,W) scratch, needed iff ksize > 1. */
+int dsm_corr1d_bwd(const void* grad_out, const void* fL, const void* fR,
+                   void* dfL, void* dfR, void* tmp,
+                   int B, int C, int H, int W, int D, int stride, int ksize,
+                   int dtype, dsm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * (a2,a3) concatenation cost volume.  Replaces the inline loops of
+ * models/gcnet.py:130-135 (mask_left = 0) and
+ * models/psmnet/stackhourglass.py:124-133 (mask_left = 1):
+ *   vol[b,   c, d,y,x] = fL[b,c,y,x]        (x >= d, or every x when !mask_left)
+ *   vol[b, C+c, d,y,x] = fR[b,c,y,x - d]    (x >= d)          zero elsewhere
+ * fL, fR: (B,C,H,W); vol: (B,2C,D,H,W) in `layout`; written in one pass, no memset.
+ * ------------------------------------------------------------------------- */
+int dsm_concat_volume_fwd(const void* fL, const void* fR, void* vol,
+                          int B, int C, int H, int W, int D,
+                          int mask_left, int layout, int dtype, dsm_stream_t stream);
+
+/* gvol: (B,2C,D,H,W) in `layout`; dfL, dfR: (B,C,H,W), fully overwritten. */
+int dsm_concat_volume_bwd(const void* gvol, void* dfL, void* dfR,
+                          int B, int C, int H, int W, int D,
+                          int mask_left, int layout, int dtype, dsm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * (a6,a7) soft-argmin disparity regression, fused.  Replaces
+ *   PSMNet: F.upsample(trilinear) -> F.softmax -> disparityregression
+ *           (stackhourglass.py:152-166, submodule.py:56-63):  negate = 0,
+ *           cost (B,Dc,Hc,Wc) upsampled to (D,H,W) on the fly;
+ *   GCNet:  Softmax2d(-x) -> matmul(arange) (models/gcnet.py:104-111): negate = 1,
+ *           (Dc,Hc,Wc) == (D,H,W), no interpolation.
+ *   disp[b,y,x] = sum_d d * softmax_d(+-cost_up[b,d,y,x])
+ * cost: (B,Dc,Hc,Wc); disp: (B,H,W); stats: (B,2,H,W) or NULL -- per-pixel
+ * softmax max and normaliser, saved for the backward pass.
+ * align_corners follows torch.nn.functional.interpolate (0 = what F.upsample
+ * resolves to on torch >= 0.4; see DESIGN.md "version drift").
+ * ------------------------------------------------------------------------- */
+int dsm_soft_argmin_fwd(const void* cost, void* disp, void* stats,
+                        int B, int Dc, int Hc, int Wc, int D, int H, int W,
+                        int negate, int align_corners, int dtype, dsm_stream_t stream);
+
+/* gdisp: (B,H,W); dcost: (B,Dc,Hc,Wc), fully overwritten (zeroed on `stream`
+ * first when the upsampling adjoint accumulates into it). */
+int dsm_soft_argmin_bwd(const void* cost, const void* disp, const void* stats,
+                        const void* gdisp, void* dcost,
+                        int B, int Dc, int Hc, int Wc, int D, int H, int W,
+                        int negate, int align_corners, int dtype, dsm_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * (a4,a5) 3-D convolution block, k = 3, fused epilogue.  Replaces
+ *   convbn_3d (+ReLU, +skip)            models/psmnet/submodule.py:16-19,
+ *                                       stackhourglass.py:22-62,73-98,135-149
+ *   conv3d_bn / deconv3d_bn             models/util_conv.py:150-179,
+ *   myadd_3d / myAdd3d (crop + add)     stackhourglass.py:10-20, util_fun.py:41-50
+ *   y = relu?( conv(x, w) * scale[co] + shift[co]  (+ residual, cropped) )
+ * `scale`/`shift` carry the folded eval-mode BatchNorm and the conv bias.
+ * transposed = 0: Conv3d(k=3, padding=1, stride in {1,2})
+ * transposed = 1: ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1)
+ * Activations are DSM_NDHWC, fp32.  (Do,Ho,Wo) may be smaller than the natural
+ * output size: only that corner is computed -- this is the crop of myadd_3d.
+ * Contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32 products and sums).
+ * ------------------------------------------------------------------------- */
+typedef struct dsm_conv3d_args {
+  const void*  x;         /* (B,Di,Hi,Wi,Cin)                                   */
+  const void*  w_packed;  /* from dsm_conv3d_pack_weights                        */
+  const float* scale;     /* [Cout] or NULL (= 1)                                */
+  const float* shift;     /* [Cout] or NULL (= 0)                                */
+  const void*  residual;  /* (B,Dr,Hr,Wr,Cout) or NULL                           */
+  void*        y;         /* (B,Do,Ho,Wo,Cout)                                   */
+  int B, Cin, Cout;
+  int Di, Hi, Wi;
+  int Do, Ho, Wo;
+  int Dr, Hr, Wr;
+  int stride;
+  int transposed;
+  int relu;
+} dsm_conv3d_args;
+
+/* bytes of the packed (MFMA-fragment-ordered) weight buffer */
+size_t dsm_conv3d_packed_weight_bytes(int Cin, int Cout, int transposed);
+
+/* w_torch: torch layout, (Cout,Cin,3,3,3) or, transposed, (Cin,Cout,3,3,3). */
+int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed,
+                            int Cin, int Cout, int transposed, dsm_stream_t stream);
+
+int dsm_conv3d_fwd(const dsm_conv3d_args* args, dsm_stream_t stream);
+
+/* NCDHW <-> NDHWC repack of an fp32 volume (used at the boundary with stock
+ * torch modules that want contiguous NCDHW). to_ndhwc = 1: src NCDHW. */
+int dsm_volume_relayout(const void* src, void* dst, int B, int C, int D, int H, int W,
+                        int to_ndhwc, dsm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSMNET_HIP_H */

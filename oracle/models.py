@@ -1,0 +1,428 @@
+"""Oracle restatements of the reference's four cost-volume networks (CPU, fp32).
+
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.
+
+The networks are written *functionally over a reference-format state dict*:
+every parameter is looked up by the key the reference's ``nn.Module`` tree
+gives it (``dres0.0.0.weight``, ``layer3d.l33.1.running_mean`` ...), so running
+the oracle on a state dict also checks the checkpoint key contract
+(SURVEY.md section 8b).  ``init_state(name)`` runs the same code once on the
+``meta`` device to create a state dict with the reference's initialisation
+rules; ``tests/golden/make_goldens.py`` loads that dict *strictly* into the
+real reference modules, which pins names and shapes against the reference.
+
+Reference entry points restated:
+  psmnet       models/psmnet/stackhourglass.py:117-168, submodule.py:65-140
+  gcnet        models/gcnet.py:14-137
+  dispnetcorr  models/dispnetcorr.py:13-134
+  iresnet      models/iresnet.py:17-201, utils/imwrap.py:37-72
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+_CONV = {2: (F.conv2d, F.conv_transpose2d), 3: (F.conv3d, F.conv_transpose3d)}
+
+
+class Net(object):
+    """Parameter context shared by build mode and run mode.
+
+    Build mode (``sd=None``): tensors flowing through are ``meta`` tensors, so
+    only shapes propagate; every parameter asked for is created with the
+    reference's initialisation (He-normal for Conv2d/Conv3d weights --
+    ``models/util_conv.py:32-53``, ``stackhourglass.py:100-112`` -- torch's
+    default for biases and transposed convolutions, BN gamma=1 beta=0).
+    Run mode: parameters are read from ``sd``; ``training=True`` uses batch
+    statistics and updates the running ones in place, as ``nn.BatchNorm*`` does.
+    """
+
+    def __init__(self, sd=None, training=False, seed=0):
+        self.build = sd is None
+        self.sd = OrderedDict() if sd is None else sd
+        self.training = training
+        self.gen = torch.Generator().manual_seed(seed) if self.build else None
+
+    # -- parameters ---------------------------------------------------------
+    # Draw in float64 and round once to float32: the integer stream of the CPU
+    # generator is platform independent, and the rounding hides last-ulp libm
+    # differences, so the same seed gives the same weights on the GPU box.
+    def _uniform(self, shape, bound):
+        u = torch.rand(shape, generator=self.gen, dtype=torch.float64)
+        return ((u * 2 - 1) * bound).float()
+
+    def _normal(self, shape, std):
+        return (torch.randn(shape, generator=self.gen, dtype=torch.float64) * std).float()
+
+    def _make_conv(self, key, wshape, nd, k, cout, transposed, bias, gain):
+        if key + ".weight" in self.sd:
+            return
+        fan_in = wshape[1] * k ** nd
+        if transposed:
+            w = self._uniform(wshape, 1.0 / math.sqrt(fan_in))
+        else:
+            w = self._normal(wshape, math.sqrt(2.0 / (k ** nd * cout)))
+        self.sd[key + ".weight"] = w * gain
+        if bias:
+            self.sd[key + ".bias"] = self._uniform((cout,), 1.0 / math.sqrt(fan_in))
+
+    def conv(self, x, key, cout, k=3, stride=1, pad=None, dil=1, bias=False, nd=2,
+             transposed=False, out_pad=0, gain=1.0):
+        cin = x.shape[1]
+        pad = (k - 1) // 2 if pad is None else pad
+        wshape = ((cin, cout) if transposed else (cout, cin)) + (k,) * nd
+        if self.build:
+            self._make_conv(key, wshape, nd, k, cout, transposed, bias, gain)
+        w = self.sd[key + ".weight"]
+        assert tuple(w.shape) == wshape, (key, tuple(w.shape), wshape)
+        b = self.sd.get(key + ".bias") if bias else None
+        if x.is_meta:
+            w = w.to("meta")
+            b = None if b is None else b.to("meta")
+        fwd, tr = _CONV[nd]
+        if transposed:
+            return tr(x, w, b, stride=stride, padding=pad, output_padding=out_pad)
+        return fwd(x, w, b, stride=stride, padding=pad, dilation=dil)
+
+    def bn(self, x, key, eps=1e-5, momentum=0.1):
+        c = x.shape[1]
+        if self.build and key + ".weight" not in self.sd:
+            self.sd[key + ".weight"] = torch.ones(c)
+            self.sd[key + ".bias"] = torch.zeros(c)
+            self.sd[key + ".running_mean"] = torch.zeros(c)
+            self.sd[key + ".running_var"] = torch.ones(c)
+            self.sd[key + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+        if x.is_meta:
+            return x
+        if self.training and key + ".num_batches_tracked" in self.sd:
+            self.sd[key + ".num_batches_tracked"] += 1
+        return F.batch_norm(x, self.sd[key + ".running_mean"], self.sd[key + ".running_var"],
+                            self.sd[key + ".weight"], self.sd[key + ".bias"],
+                            self.training, momentum, eps)
+
+
+def _cat2d(*seq):
+    """``myCat2d`` (models/util_fun.py:7-15): crop to the common h, w, then cat."""
+    h = min(t.shape[2] for t in seq)
+    w = min(t.shape[3] for t in seq)
+    return torch.cat([t[:, :, :h, :w] for t in seq], dim=1)
+
+
+def _up2(x):
+    """``nn.Upsample(scale_factor=2, mode='bilinear')`` (dispnetcorr.py:22)."""
+    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+
+
+# =============================================================================
+# PSMNet (stacked hourglass)
+# =============================================================================
+def psmnet_features(n, x, p="feature_extraction"):
+    """``feature_extraction`` -- models/psmnet/submodule.py:65-140.
+
+    ``convbn`` there pads by ``dilation`` whatever the kernel (``:10-13``), so the
+    1x1 branch convolutions grow their input by one pixel per side.
+    """
+    def cbn(t, key, cout, k, stride, dil):
+        return n.bn(n.conv(t, key + ".0", cout, k, stride, pad=dil, dil=dil), key + ".1")
+
+    for idx, s in ((0, 2), (2, 1), (4, 1)):
+        x = F.relu(cbn(x, "%s.firstconv.%d" % (p, idx), 32, 3, s, 1))
+
+    def layer(t, name, planes, blocks, stride, dil):
+        for b in range(blocks):
+            key = "%s.%s.%d" % (p, name, b)
+            s = stride if b == 0 else 1
+            y = F.relu(cbn(t, key + ".conv1.0", planes, 3, s, dil))
+            y = cbn(y, key + ".conv2", planes, 3, 1, dil)
+            if b == 0 and (stride != 1 or t.shape[1] != planes):
+                t = n.bn(n.conv(t, key + ".downsample.0", planes, 1, stride, pad=0),
+                         key + ".downsample.1")
+            t = y + t
+        return t
+
+    x = layer(x, "layer1", 32, 3, 1, 1)
+    raw = layer(x, "layer2", 64, 16, 2, 1)
+    x = layer(raw, "layer3", 128, 3, 1, 1)
+    skip = layer(x, "layer4", 128, 3, 1, 2)
+    size = tuple(skip.shape[2:])
+    branches = []
+    for idx, pool in ((1, 64), (2, 32), (3, 16), (4, 8)):
+        b = F.avg_pool2d(skip, pool, stride=pool)
+        b = F.relu(cbn(b, "%s.branch%d.1" % (p, idx), 32, 1, 1, 1))
+        branches.append(F.interpolate(b, size=size, mode="bilinear", align_corners=False))
+    x = torch.cat([raw, skip, branches[3], branches[2], branches[1], branches[0]], dim=1)
+    x = F.relu(cbn(x, p + ".lastconv.0", 128, 3, 1, 1))
+    return n.conv(x, p + ".lastconv.2", 32, 1, 1, pad=0)
+
+
+def _cbn3(n, x, key, cout, stride=1):
+    """``convbn_3d`` -- submodule.py:16-19."""
+    return n.bn(n.conv(x, key + ".0", cout, 3, stride, nd=3), key + ".1")
+
+
+def _hourglass(n, x, key, presqu, postsqu):
+    """``hourglass.forward`` -- stackhourglass.py:43-62."""
+    c = x.shape[1]
+    out = F.relu(_cbn3(n, x, key + ".conv1.0", 2 * c, 2))
+    pre = _cbn3(n, out, key + ".conv2", 2 * c)
+    pre = F.relu(pre + postsqu) if postsqu is not None else F.relu(pre)
+    out = F.relu(_cbn3(n, pre, key + ".conv3.0", 2 * c, 2))
+    out = F.relu(_cbn3(n, out, key + ".conv4.0", 2 * c))
+    up = n.bn(n.conv(out, key + ".conv5.0", 2 * c, 3, 2, nd=3, transposed=True, out_pad=1),
+              key + ".conv5.1")
+    post = F.relu(ops.crop_add(up, presqu if presqu is not None else pre))
+    out = n.bn(n.conv(post, key + ".conv6.0", c, 3, 2, nd=3, transposed=True, out_pad=1),
+               key + ".conv6.1")
+    return out, pre, post
+
+
+def psmnet_trunk(n, vol):
+    """3-D regularisation, stackhourglass.py:135-149.  Returns (cost1, cost2, cost3)."""
+    c0 = F.relu(_cbn3(n, vol, "dres0.0", 32))
+    c0 = F.relu(_cbn3(n, c0, "dres0.2", 32))
+    r = F.relu(_cbn3(n, c0, "dres1.0", 32))
+    c0 = ops.crop_add(_cbn3(n, r, "dres1.2", 32), c0)
+    out1, pre1, post1 = _hourglass(n, c0, "dres2", None, None)
+    out1 = ops.crop_add(out1, c0)
+    out2, _pre2, post2 = _hourglass(n, out1, "dres3", pre1, post1)
+    out2 = ops.crop_add(out2, c0)
+    out3, _pre3, _post3 = _hourglass(n, out2, "dres4", pre1, post2)   # pre1, not pre2 (:144)
+    out3 = ops.crop_add(out3, c0)
+
+    def classif(t, key):
+        t = F.relu(_cbn3(n, t, key + ".0", 32))
+        return n.conv(t, key + ".2", 1, 3, 1, nd=3)
+
+    cost1 = classif(out1, "classif1")
+    cost2 = classif(out2, "classif2") + cost1
+    cost3 = classif(out3, "classif3") + cost2
+    return cost1, cost2, cost3
+
+
+def psmnet(n, left, right, maxdisp=192):
+    """``PSMNet.forward`` -- stackhourglass.py:117-168.  Returns [pred3, pred2, pred1]."""
+    fl = psmnet_features(n, left)
+    fr = psmnet_features(n, right)
+    vol = ops.concat_volume(fl, fr, maxdisp // 4, mask_left=True)
+    cost1, cost2, cost3 = psmnet_trunk(n, vol)
+    if left.is_meta:
+        return None
+    size = (maxdisp, left.shape[2], left.shape[3])
+    return [ops.soft_argmin(c, size) for c in (cost3, cost2, cost1)]
+
+
+# =============================================================================
+# GCNet
+# =============================================================================
+def gcnet_features(n, x, p="layer2d"):
+    """``feature2d`` -- models/gcnet.py:14-29 (ResNet blocks: util_conv.py:181-210)."""
+    x = F.relu(n.bn(n.conv(x, p + ".conv1.0", 32, 5, 2, bias=True), p + ".conv1.1"))
+    for i in range(8):
+        key = "%s.block1.%d" % (p, i)
+        y = F.relu(n.bn(n.conv(x, key + ".conv1", 32, 3), key + ".bn1"))
+        y = n.bn(n.conv(y, key + ".conv2", 32, 3), key + ".bn2")
+        x = F.relu(y + x)
+    return n.conv(x, p + ".conv2", 32, 3, bias=True)
+
+
+def gcnet_trunk(n, x, p="layer3d"):
+    """``feature3d.forward`` up to ``x37`` -- models/gcnet.py:65-101."""
+    def c(t, name, cout, stride=1):
+        key = "%s.%s" % (p, name)
+        return F.relu(n.bn(n.conv(t, key + ".0", cout, 3, stride, bias=True, nd=3), key + ".1"))
+
+    def dc(t, name, cout):
+        key = "%s.%s" % (p, name)
+        y = n.conv(t, key + ".0", cout, 3, 2, bias=True, nd=3, transposed=True, out_pad=1)
+        return F.relu(n.bn(y, key + ".1"))
+
+    x18 = x
+    x21 = c(x18, "l21", 64, 2)
+    x24 = c(x21, "l24", 64, 2)
+    x27 = c(x24, "l27", 64, 2)
+    x32 = c(c(c(x27, "l30", 128, 2), "l31", 128), "l32", 128)
+    x29 = c(c(x27, "l28", 64), "l29", 64)
+    x33 = ops.crop_add(dc(x32, "l33", 64), x29)
+    x26 = c(c(x24, "l25", 64), "l26", 64)
+    x34 = ops.crop_add(dc(x33, "l34", 64), x26)
+    x23 = c(c(x21, "l22", 64), "l23", 64)
+    x35 = ops.crop_add(dc(x34, "l35", 64), x23)
+    x20 = c(c(x18, "l19", 32), "l20", 32)
+    x36 = ops.crop_add(dc(x35, "l36", 32), x20)
+    return n.conv(x36, p + ".l37", 1, 3, 2, bias=True, nd=3, transposed=True, out_pad=1)
+
+
+def gcnet(n, imL, imR, maxdisp=192):
+    """``gcnet.forward`` -- models/gcnet.py:126-137.  Returns the (B,1,H,W) disparity."""
+    assert imL.shape == imR.shape
+    fL = gcnet_features(n, imL)
+    fR = gcnet_features(n, imR)
+    vol = ops.concat_volume(fL, fR, maxdisp // 2, mask_left=False)
+    x37 = gcnet_trunk(n, vol)
+    if imL.is_meta:
+        return None
+    disp = ops.soft_argmin(x37, None, negate=True).unsqueeze(1)
+    return disp[:, :, : imL.shape[-2], : imL.shape[-1]]
+
+
+# =============================================================================
+# DispNetC / iResNet
+# =============================================================================
+def _c2(n, x, key, cout, k=3, stride=1):
+    """``conv2d_bn`` with bias, no BN, ReLU -- util_conv.py:116-129."""
+    return F.relu(n.conv(x, key + ".0", cout, k, stride, bias=True))
+
+
+def _d2(n, x, key, cout, k=4, stride=2):
+    """``deconv2d_bn`` with bias, no BN, ReLU -- util_conv.py:132-147."""
+    p = (k - 1) // 2
+    op = stride - (k - 2 * p)
+    return F.relu(n.conv(x, key + ".0", cout, k, stride, pad=p, bias=True,
+                         transposed=True, out_pad=op))
+
+
+def _pr(n, x, key):
+    """Disparity prediction head: plain 3x3 conv to 1 channel, weights x0.1 at init
+    (dispnetcorr.py:63-64)."""
+    return n.conv(x, key, 1, 3, 1, bias=True, gain=0.1)
+
+
+def dispnetcorr(n, imL, imR, maxdisp=192, mode="train"):
+    """``dispnetcorr.forward`` -- models/dispnetcorr.py:66-134.
+    Returns (scales, outputs) with outputs = [pr0, pr1, ..., pr6]."""
+    assert imL.shape == imR.shape
+    maxD = max(maxdisp, imL.shape[-1])
+    c1L, c1R = _c2(n, imL, "conv1", 64, 7, 2), _c2(n, imR, "conv1", 64, 7, 2)
+    c2L, c2R = _c2(n, c1L, "conv2", 128, 5, 2), _c2(n, c1R, "conv2", 128, 5, 2)
+    corr = ops.corr1d(c2L, c2R, 41, 1, 1)
+    redir = _c2(n, c2L, "redir", 64, 1, 1)
+    c3b = _c2(n, _c2(n, torch.cat([corr, redir], 1), "conv3a", 256, 5, 2), "conv3b", 256)
+    c4b = _c2(n, _c2(n, c3b, "conv4a", 512, 3, 2), "conv4b", 512)
+    c5b = _c2(n, _c2(n, c4b, "conv5a", 512, 3, 2), "conv5b", 512)
+    c6b = _c2(n, _c2(n, c5b, "conv6a", 1024, 3, 2), "conv6b", 1024)
+    skips = {5: c5b, 4: c4b, 3: c3b, 2: c2L, 1: c1L}
+    width = {5: 512, 4: 256, 3: 128, 2: 64, 1: 32}
+    pr = _pr(n, c6b, "pr6")
+    outs, feat = [pr], c6b
+    for lvl in (5, 4, 3, 2, 1):
+        up = _d2(n, feat, "deconv%d" % lvl, width[lvl])
+        feat = _c2(n, _cat2d(up, _up2(pr), skips[lvl]), "iconv%d" % lvl, width[lvl])
+        pr = _pr(n, feat, "pr%d" % lvl)
+        outs.insert(0, pr)
+    outs.insert(0, _up2(pr)[:, :, : imL.shape[-2], : imL.shape[-1]])
+    if mode == "test" and not imL.is_meta:
+        outs[-1] = outs[-1].clamp(1e-6, maxD)      # the reference clamps out[-1] (:132)
+    return list(range(7)), outs
+
+
+def imwarp(im_src, disp):
+    """``imwrap_BCHW(im_src, disp)`` with its defaults -- utils/imwrap.py:37-72.
+    Consumes one ``torch.rand(1)`` from the global generator (``:70``)."""
+    bn, _, h0, w0 = im_src.shape
+    _, c, h, w = disp.shape
+    assert c == 1 and min(h, w, h0, w0) > 1
+    x1 = -1.0 + (w - 1) * 2.0 / (w0 - 1)
+    y1 = -1.0 + (h - 1) * 2.0 / (h0 - 1)
+    gx = torch.linspace(-1.0, x1, w).view(1, 1, w).expand(bn, h, w)
+    gy = torch.linspace(-1.0, y1, h).view(1, h, 1).expand(bn, h, w)
+    gx = gx.type_as(im_src) - disp.squeeze(1) * 2.0 / (w0 - 1)
+    grid = torch.stack([gx, gy.type_as(im_src)], dim=3)
+    delt = 1e-4 * (torch.rand(1)[0] + 0.1)
+    return F.grid_sample(im_src + delt, grid, mode="bilinear", padding_mode="zeros",
+                         align_corners=False)
+
+
+def iresnet(n, imL, imR, maxdisp=192, mode="train", iters=1):
+    """``iresnet.forward`` -- models/iresnet.py:86-201."""
+    assert imL.shape == imR.shape
+    maxD = max(maxdisp, imL.shape[-1])
+    H, W = imL.shape[-2], imL.shape[-1]
+    c1L, c1R = _c2(n, imL, "conv1", 64, 7, 2), _c2(n, imR, "conv1", 64, 7, 2)
+    c2L, c2R = _c2(n, c1L, "conv2", 128, 5, 2), _c2(n, c1R, "conv2", 128, 5, 2)
+
+    def stem(c1, c2):
+        d1 = _d2(n, c1, "deconv1_s", 32, 4, 2)[:, :, :H, :W]
+        d2 = _d2(n, c2, "deconv2_s", 32, 8, 4)
+        return _c2(n, _cat2d(d1, d2), "conv_de1_de2", 32, 1, 1)
+
+    sL, sR = stem(c1L, c2L), stem(c1R, c2R)
+    corr = ops.corr1d(c2L, c2R, 81, 1, 1)
+    redir = _c2(n, c2L, "redir", 64, 1, 1)
+    c3 = _c2(n, _c2(n, torch.cat([corr, redir], 1), "conv3", 256, 3, 2), "conv3_1", 256)
+    c4 = _c2(n, _c2(n, c3, "conv4", 512, 3, 2), "conv4_1", 512)
+    c5 = _c2(n, _c2(n, c4, "conv5", 512, 3, 2), "conv5_1", 512)
+    c6 = _c2(n, _c2(n, c5, "conv6", 1024, 3, 2), "conv6_1", 1024)
+    skips = {5: c5, 4: c4, 3: c3, 2: c2L, 1: c1L, 0: sL}
+    width = {5: 512, 4: 256, 3: 128, 2: 64, 1: 32, 0: 32}
+    pr = _pr(n, c6, "pr6")
+    outs, scales, feat, keep = [pr], [6], c6, {}
+    for lvl in (5, 4, 3, 2, 1, 0):
+        up = _d2(n, feat, "deconv%d" % lvl, width[lvl])
+        feat = _c2(n, _cat2d(up, _up2(pr), skips[lvl]), "iconv%d" % lvl, width[lvl])
+        if lvl == 0:
+            pr = n.conv(feat, "pr0", 1, 3, 1, bias=True)      # pr0 is not scaled at init (:83)
+        else:
+            pr = _pr(n, feat, "pr%d" % lvl)
+        keep[lvl] = pr
+        outs.insert(0, pr)
+        scales.insert(0, lvl)
+    r_pr2, r_pr1, r_pr0 = keep[2], keep[1], keep[0]
+    for _ in range(iters):
+        if imL.is_meta:
+            warped = sR
+        else:
+            warped = imwarp(sR, -r_pr0)
+        err = torch.abs(sL - warped)
+        r0 = _c2(n, _cat2d(err, r_pr0, sL), "r_conv0", 32)
+        r1 = _c2(n, r0, "r_conv1", 64, 3, 2)
+        ccL, ccR = _c2(n, c1L, "c_conv1", 64), _c2(n, c1R, "c_conv1", 64)
+        rc = ops.corr1d(ccL, ccR, 41, 2, 3)
+        r11 = _c2(n, _cat2d(r1, rc), "r_conv1_1", 64)
+        r21 = _c2(n, _c2(n, r11, "r_conv2", 128, 3, 2), "r_conv2_1", 128)
+        res2 = _pr(n, r21, "r_res2")
+        r_pr2 = r_pr2 + res2
+        outs.insert(0, r_pr2); scales.insert(0, 2)
+        ri1 = _c2(n, _cat2d(_d2(n, r21, "r_deconv1", 64), _up2(res2), r11), "r_iconv1", 64)
+        res1 = _pr(n, ri1, "r_res1")
+        r_pr1 = r_pr1 + res1
+        outs.insert(0, r_pr1); scales.insert(0, 1)
+        ri0 = _c2(n, _cat2d(_d2(n, ri1, "r_deconv0", 32), _up2(res1), r0), "r_iconv0", 32)
+        res0 = _pr(n, ri0, "r_res0")
+        r_pr0 = r_pr0 + res0
+        outs.insert(0, r_pr0); scales.insert(0, 0)
+    if mode == "test" and not imL.is_meta:
+        outs[-1] = outs[-1].clamp(1e-6, maxD)
+    return scales, outs
+
+
+FORWARD = {"psmnet": psmnet, "gcnet": gcnet, "dispnetcorr": dispnetcorr, "iresnet": iresnet}
+_BUILD_HW = {"psmnet": (256, 512), "gcnet": (64, 128), "dispnetcorr": (256, 512),
+             "iresnet": (256, 512)}
+
+
+def init_state(name, seed=0, maxdisp=192):
+    """Create a reference-format state dict for ``name`` with the reference's
+    initialisation rules (shapes come from one pass on the meta device)."""
+    n = Net(None, seed=seed)
+    h, w = _BUILD_HW[name]
+    x = torch.empty(1, 3, h, w, device="meta")
+    FORWARD[name](n, x, x, maxdisp)
+    return n.sd
+
+
+def forward(name, sd, imL, imR, maxdisp=192, training=False, **kw):
+    """Run the oracle network ``name`` on CPU with parameters ``sd``."""
+    return FORWARD[name](Net(sd, training=training), imL, imR, maxdisp, **kw)
+
+
+def calibrate_bn(name, sd, imL, imR, maxdisp=192, passes=1):
+    """Populate BN running statistics with train-mode passes (SURVEY.md section 7,
+    "Parity fragility"): random-init weights with running stats 0/1 saturate the
+    soft-argmin, so end-to-end parity uses calibrated statistics."""
+    with torch.no_grad():
+        for _ in range(passes):
+            forward(name, sd, imL, imR, maxdisp, training=True)
+    return sd
