@@ -206,9 +206,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
             const int xo = tx0 + (i & 3) + 8 * (i >> 2) + 4 * h;
             if (xo >= p.Wo) continue;
             float v = acc[m][n][i] * sc + sh;
+            if (p.relu == 2) v = fmaxf(v, 0.f);
             if (p.res)
               v += p.res[((((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo) * p.Cout + co];
-            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.relu == 1) v = fmaxf(v, 0.f);
             p.y[((((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo) * p.Cout + co] = v;
           }
         }
@@ -318,9 +319,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
           const int xo = 2 * xm + px;
           if (xm >= p.Wi || xo >= p.Wo) continue;
           float v = acc[m][n][i] * sc + sh;
+          if (p.relu == 2) v = fmaxf(v, 0.f);
           if (p.res)
             v += p.res[((((long)tb * p.Dr + zo) * p.Hr + yo) * p.Wr + xo) * p.Cout + co];
-          if (p.relu) v = fmaxf(v, 0.f);
+          if (p.relu == 1) v = fmaxf(v, 0.f);
           p.y[((((long)tb * p.Do + zo) * p.Ho + yo) * p.Wo + xo) * p.Cout + co] = v;
         }
       }
@@ -384,8 +386,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3d_cout1_kernel(ConvParams p) {
     const int yo = ty0 + ty, xo = tx0 + r;
     if (yo < p.Ho && xo < p.Wo) {
       float v = acc * (p.scale ? p.scale[0] : 1.f) + (p.shift ? p.shift[0] : 0.f);
+      if (p.relu == 2) v = fmaxf(v, 0.f);
       if (p.res) v += p.res[(((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo];
-      if (p.relu) v = fmaxf(v, 0.f);
+      if (p.relu == 1) v = fmaxf(v, 0.f);
       p.y[(((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo] = v;
     }
   }
@@ -423,8 +426,9 @@ __global__ __launch_bounds__(NTHREADS) void deconv3d_cout1_kernel(ConvParams p) 
     }
   }
   float v = acc * (p.scale ? p.scale[0] : 1.f) + (p.shift ? p.shift[0] : 0.f);
+  if (p.relu == 2) v = fmaxf(v, 0.f);
   if (p.res) v += p.res[(((long)b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo];
-  if (p.relu) v = fmaxf(v, 0.f);
+  if (p.relu == 1) v = fmaxf(v, 0.f);
   p.y[(((long)b * p.Do + zo) * p.Ho + yo) * p.Wo + xo] = v;
 }
 

@@ -1,0 +1,105 @@
+"""PSMNet building blocks with the reference's names and constructor signatures
+(models/psmnet/submodule.py of sunshinnnn/DSMnet), MI355X-backed where the hot path runs.
+
+  convbn_3d            -> blocks3d.ConvBN3d (same children: '0' Conv3d, '1' BatchNorm3d)
+  disparityregression  -> HIP expectation over the disparity axis (submodule.py:56-63)
+  convbn / BasicBlock / feature_extraction -- the 2-D tower, out of the hot path
+      ("stock 2-D layers, use torch as is"); same module tree so
+      reference checkpoints load.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import costvolume as cv
+from ...blocks3d import ConvBN3d
+
+
+def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
+    # the reference pads by `dilation` whatever `pad` says (submodule.py:10-13); kept.
+    del pad
+    return nn.Sequential(
+        nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
+                  padding=dilation, dilation=dilation, bias=False),
+        nn.BatchNorm2d(out_planes))
+
+
+def convbn_3d(in_planes, out_planes, kernel_size, stride, pad):
+    conv = nn.Conv3d(in_planes, out_planes, kernel_size=kernel_size, padding=pad,
+                     stride=stride, bias=False)
+    return ConvBN3d(conv, nn.BatchNorm3d(out_planes))
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride, downsample, pad, dilation):
+        super(BasicBlock, self).__init__()
+        self.conv1 = nn.Sequential(convbn(inplanes, planes, 3, stride, pad, dilation),
+                                   nn.ReLU(inplace=True))
+        self.conv2 = convbn(planes, planes, 3, 1, pad, dilation)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        y = self.conv2(self.conv1(x))
+        return y + (x if self.downsample is None else self.downsample(x))
+
+
+class disparityregression(nn.Module):
+    """``forward(x)``: x is a (B, D, H, W) probability volume; returns sum_d d * x[:, d].
+
+    PSMNet's heads no longer call this (the softmax and the upsampling are fused into
+    ``costvolume.soft_argmin``); it is kept, by name, for callers that still hold
+    probabilities.  sum_d d*p_d == soft-argmin of log p, so it runs on the same kernel."""
+
+    def __init__(self, maxdisp):
+        super(disparityregression, self).__init__()
+        self.maxdisp = maxdisp
+
+    def forward(self, x):
+        return cv.soft_argmin(torch.log(x.clamp_min(1e-38)), None, negate=False)
+
+
+class feature_extraction(nn.Module):
+    """2-D SPP tower, (B,3,H,W) -> (B,32,H/4,W/4).  Stock torch layers (MIOpen)."""
+
+    def __init__(self):
+        super(feature_extraction, self).__init__()
+        self.inplanes = 32
+        stem = []
+        for cin, stride in ((3, 2), (32, 1), (32, 1)):
+            stem += [convbn(cin, 32, 3, stride, 1, 1), nn.ReLU(inplace=True)]
+        self.firstconv = nn.Sequential(*stem)
+        self.layer1 = self._make_layer(BasicBlock, 32, 3, 1, 1, 1)
+        self.layer2 = self._make_layer(BasicBlock, 64, 16, 2, 1, 1)
+        self.layer3 = self._make_layer(BasicBlock, 128, 3, 1, 1, 1)
+        self.layer4 = self._make_layer(BasicBlock, 128, 3, 1, 1, 2)
+        for idx, pool in ((1, 64), (2, 32), (3, 16), (4, 8)):
+            setattr(self, "branch%d" % idx, nn.Sequential(
+                nn.AvgPool2d((pool, pool), stride=(pool, pool)),
+                convbn(128, 32, 1, 1, 0, 1), nn.ReLU(inplace=True)))
+        self.lastconv = nn.Sequential(
+            convbn(320, 128, 3, 1, 1, 1), nn.ReLU(inplace=True),
+            nn.Conv2d(128, 32, kernel_size=1, padding=0, stride=1, bias=False))
+
+    def _make_layer(self, block, planes, blocks, stride, pad, dilation):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1,
+                          stride=stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample, pad, dilation)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.layer1(self.firstconv(x))
+        raw = self.layer2(x)
+        skip = self.layer4(self.layer3(raw))
+        size = skip.shape[2:]
+        pyramid = [F.interpolate(getattr(self, "branch%d" % i)(skip), size=size,
+                                 mode="bilinear", align_corners=False) for i in (4, 3, 2, 1)]
+        return self.lastconv(torch.cat([raw, skip] + pyramid, dim=1))

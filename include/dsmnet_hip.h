@@ -112,7 +112,10 @@ int dsm_soft_argmin_bwd(const void* cost, const void* disp, const void* stats,
  *                                       stackhourglass.py:22-62,73-98,135-149
  *   conv3d_bn / deconv3d_bn             models/util_conv.py:150-179,
  *   myadd_3d / myAdd3d (crop + add)     stackhourglass.py:10-20, util_fun.py:41-50
- *   y = relu?( conv(x, w) * scale[co] + shift[co]  (+ residual, cropped) )
+ *   relu = 1:  y = relu( conv(x, w) * scale[co] + shift[co]  (+ residual, cropped) )   PSMNet order
+ *   relu = 2:  y = relu( conv(x, w) * scale[co] + shift[co] )  (+ residual, cropped)   GCNet order
+ *              (models/gcnet.py:78-96: the ReLU sits inside deconv3d_bn, myAdd3d follows)
+ *   relu = 0:  no activation
  * `scale`/`shift` carry the folded eval-mode BatchNorm and the conv bias.
  * transposed = 0: Conv3d(k=3, padding=1, stride in {1,2})
  * transposed = 1: ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1)
@@ -133,7 +136,7 @@ typedef struct dsm_conv3d_args {
   int Dr, Hr, Wr;
   int stride;
   int transposed;
-  int relu;
+  int relu;               /* 0 none, 1 after the skip add, 2 before it */
 } dsm_conv3d_args;
 
 /* bytes of the packed (MFMA-fragment-ordered) weight buffer */

@@ -1,0 +1,47 @@
+"""Where does the end-to-end PSMNet difference come from?  Compares the CPU fp32 oracle
+and the MI355X path, stage by stage, against an fp64 run of the oracle (the truth)."""
+import sys, time
+sys.path.insert(0, '.')
+import torch
+from oracle import models as OM, ops as OO
+from tests.golden.make_goldens import images
+from tests.conftest import Golden
+from dsmnet_amd.models import model_create_by_name
+from dsmnet_amd import costvolume as cv
+
+from tests.helpers import golden_state
+g = Golden("e2e")
+sd, cfg = golden_state(g, "psmnet")          # calibrated BN + calibrated heads
+# argv[1]: extra factor on the heads; 1/7.237778e-04 = 1381.6 restores the raw reference init
+scale_heads = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+OM.apply_head_scale("psmnet", sd, scale_heads)
+sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+imL, imR = images(cfg["image_seed"], *cfg["hw"])
+size = (192, 256, 512)
+def err(a, b): return (a.double().cpu() - b.double().cpu()).abs().max().item()
+with torch.no_grad():
+    t = time.time()
+    n64 = OM.Net(sd64)
+    fl64, fr64 = OM.psmnet_features(n64, imL.double()), OM.psmnet_features(n64, imR.double())
+    c64 = OM.psmnet_trunk(n64, OO.concat_volume(fl64, fr64, 48, True))
+    d64 = [OO.soft_argmin(c, size) for c in c64]
+    print("fp64 oracle %.1fs; |cost3| max %.2f std %.2f" % (time.time() - t, c64[2].abs().max(), c64[2].std()))
+    n32 = OM.Net(sd)
+    fl32, fr32 = OM.psmnet_features(n32, imL), OM.psmnet_features(n32, imR)
+    c32 = OM.psmnet_trunk(n32, OO.concat_volume(fl32, fr32, 48, True))
+    d32 = [OO.soft_argmin(c, size) for c in c32]
+    m = model_create_by_name("psmnet", 192); m.load_state_dict(sd); m = m.cuda().eval()
+    flg, frg = m.features(imL.cuda(), imR.cuda())
+    cg = m.regularise(cv.concat_volume(flg, frg, 48, True))
+    dg = [cv.soft_argmin(c, size) for c in cg]
+    # trunk only, fed with the CPU-fp32 features
+    cg2 = m.regularise(cv.concat_volume(fl32.cuda(), fr32.cuda(), 48, True))
+    dg2 = [cv.soft_argmin(c, size) for c in cg2]
+    # head only, fed with the CPU fp32 cost
+    dg3 = [cv.soft_argmin(c.cuda(), size) for c in c32]
+    print("features  : cpu32-vs-64 %.3e   gpu-vs-64 %.3e   (|f| max %.2f)" % (err(fl32, fl64), err(flg, fl64), fl64.abs().max()))
+    for i in range(3):
+        print("cost%d     : cpu32-vs-64 %.3e   gpu-vs-64 %.3e   gpu(trunk only)-vs-cpu32 %.3e" % (i + 1, err(c32[i], c64[i]), err(cg[i], c64[i]), err(cg2[i], c32[i])))
+    for i in range(3):
+        print("disp%d     : cpu32-vs-64 %.3e   gpu-vs-64 %.3e   gpu-vs-cpu32 %.3e  trunk-only-vs-cpu32 %.3e  head-only-vs-cpu32 %.3e"
+              % (i + 1, err(d32[i], d64[i]), err(dg[i], d64[i]), err(dg[i], d32[i]), err(dg2[i], d32[i]), err(dg3[i], d32[i])))

@@ -334,6 +334,9 @@ def gen_e2e(store):
     sd = OM.init_state("gcnet", 0)
     gL, gR = images(62, 64, 128)
     OM.calibrate_bn("gcnet", sd, gL, gR)
+    gc_factor = OM.calibrate_heads("gcnet", sd, gL, gR)
+    store["e2e.gcnet.head_scale"] = np.float64(gc_factor)
+    print("  gcnet head scale %.6e" % gc_factor)
     ref = RL.fix_gcnet(mods["gcnet"].gcnet(192))
     ref.load_state_dict(sd, strict=True)
     ref.eval()
@@ -351,6 +354,9 @@ def gen_e2e(store):
     sd = OM.init_state("psmnet", 0)
     pL, pR = images(63, 256, 512)
     OM.calibrate_bn("psmnet", sd, pL, pR)
+    psm_factor = OM.calibrate_heads("psmnet", sd, pL, pR)
+    store["e2e.psmnet.head_scale"] = np.float64(psm_factor)
+    print("  psmnet head scale %.6e" % psm_factor)
     ref = mods["stackhourglass"].PSMNet(192)
     ref.load_state_dict(sd, strict=True)
     ref.eval()

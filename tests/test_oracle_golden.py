@@ -129,10 +129,8 @@ def test_blocks_match_golden(golden_blocks):
 @pytest.mark.parametrize("name", ["gcnet", "dispnetcorr"])
 def test_e2e_oracle_matches_golden(golden_e2e, name):
     from tests.golden.make_goldens import images
-    cfg = golden_e2e.meta["e2e"][name]
-    sd = OM.init_state(name, cfg["seed"])
-    for k, v in golden_e2e.arrays("e2e.%s.bn." % name).items():
-        sd[k] = torch.from_numpy(v.copy())
+    from tests.helpers import golden_state
+    sd, cfg = golden_state(golden_e2e, name)
     imL, imR = images(cfg["image_seed"], *cfg["hw"])
     with torch.no_grad():
         out = OM.forward(name, sd, imL, imR)
