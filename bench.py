@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PSMNet (stacked hourglass) forward, D=192, 384x1280, pairs/s.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+one rank per GPU.  Stereo pairs are independent, so the job shards them across ranks
+with no data-path collective (weak scaling: one pair per GPU per step); RCCL is used only
+for the timing barrier and the max-over-ranks reduction.
+
+A step = one forward pass over one synthetic KITTI-shaped pair already resident in HBM
+(2-D towers -> cost volume -> 3-D trunk -> three soft-argmin heads, all three computed as
+the reference does).  Weights: the reference's random initialisation, BN statistics and
+head scale calibrated (dsmnet_amd/calibrate.py).  Compute dtype fp32, as the reference.
+
+Rank 0 prints ONE JSON line with the throughput, the per-kernel rooflines measured live
+with HIP events on the launch stream inside the timed region, and (N=1) the CPU baseline:
+the oracle restatement of the same forward on the same weights, timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "stereo pairs/sec forward, PSMNet D=192 384×1280, at 1/2/4/8 MI355X"
+H, W, MAXDISP = 384, 1280, 192
+# MI355X ceilings (/opt/skills/guides/MI355X_MICROARCH.md): HBM3E 8.0 TB/s spec, fp32-input
+# MFMA 157.3 TFLOP/s dense (v_mfma_f32_32x32x2_f32; no xf32/TF32 on gfx950)
+PEAK_HBM_GBS = 8000.0
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def synthetic_pair(seed, device):
+    """torch.rand images, ImageNet-normalised (models/test_models_time.py:17-23,
+    myTransforms/__init__.py:8); the right view is the left one shifted by 7 px."""
+    g = torch.Generator().manual_seed(seed)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    left = torch.rand(1, 3, H, W, generator=g)
+    right = torch.roll(left, shifts=-7, dims=3)
+    return ((left - mean) / std).to(device), ((right - mean) / std).to(device)
+
+
+def kernel_rooflines(summary, steps):
+    """Per kernel: algorithmic work per launch / average launch duration vs the roofline
+    that bounds it.  HBM kernels count bytes, MFMA kernels count FLOPs."""
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            traffic = json.load(fh).get("hbm_bytes_per_launch", {})
+    out = {}
+    for name, e in summary.items():
+        n, ms, work = e["launches"], e["ms"], e["work"]
+        avg_s = ms / n * 1e-3
+        per_launch = work / n
+        mfma = "mfma" in name
+        if mfma:
+            achieved, peak, unit, bound = per_launch / avg_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s", "mfma"
+        else:
+            achieved, peak, unit, bound = per_launch / avg_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+        out[name] = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                     "frac": round(achieved / peak, 4), "traffic": traffic.get(name),
+                     "launches_per_step": n / steps, "avg_launch_us": round(avg_s * 1e6, 2),
+                     "ms_per_step": round(ms / steps, 4),
+                     "work_per_launch": per_launch}
+    return out
+
+
+def host_cores():
+    """CPUs this process may really use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                txt = fh.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            elif int(txt[0]) > 0:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    n = min(n, max(1, int(int(txt[0]) / int(fh.read()))))
+        except (OSError, ValueError, IndexError):
+            pass
+    return int(os.environ.get("DSM_BENCH_CPU_THREADS", min(n, 16)))   # 16 = the box's CPU share per GPU
+
+
+def cpu_baseline(model, left, right, gpu_preds):
+    """The oracle restatement of the same forward (same weights, same pair) on the host
+    cores.  Bounded sample: one untimed warm-up pass on a 256x512 crop, then whole
+    384x1280 passes until >= 10 s of timed work (at most 3)."""
+    from oracle import models as OM          # test infrastructure: baseline + checker only
+    torch.set_num_threads(host_cores())
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    l, r = left.cpu(), right.cpu()
+    with torch.no_grad():
+        OM.forward("psmnet", sd, l[..., :256, :512].contiguous(), r[..., :256, :512].contiguous())
+        times, preds = [], None
+        while sum(times) < 10.0 and len(times) < 3:
+            t0 = time.perf_counter()
+            preds = OM.forward("psmnet", sd, l, r, MAXDISP)
+            times.append(time.perf_counter() - t0)
+    err = max((a.cpu() - b).abs().max().item() for a, b in zip(gpu_preds, preds))
+    best = min(times)
+    return {"value": round(1.0 / best, 5), "unit": "pairs/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d whole forward pass(es) of the same 384x1280 pair, same weights "
+                      "(oracle/models.py psmnet on torch CPU fp32); best of %d; %.1f s timed"
+                      % (len(times), len(times), sum(times)),
+            "seconds_per_pair": round(best, 3)}, err
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="skip the per-launch HIP events (2 records per launch, <1%% of a step)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs one rank per GPU: launch with torch.distributed.run "
+                         "--nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    from dsmnet_amd import calibrate, costvolume
+    from dsmnet_amd.models import model_create_by_name
+    torch.manual_seed(0)
+    model = model_create_by_name("psmnet", MAXDISP).to(dev)
+    left, right = synthetic_pair(1000 + rank, dev)          # every rank owns its own pair
+    calibrate.calibrate_batchnorm(model, left, right)
+    calibrate.calibrate_psmnet_heads(model, left, right)
+    model.eval()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            preds = model(left, right)[1]
+        timer = None
+        if not args.no_kernel_timing:
+            timer = costvolume.LaunchTimer()
+            costvolume.set_timer(timer)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            preds = model(left, right)[1]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        costvolume.set_timer(None)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        result = {
+            "metric": METRIC, "value": round(world * args.steps / elapsed, 3), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PSMNet stacked-hourglass forward, D=192, 384x1280, one pair "
+                                   "per GPU per step (BASELINE configs[3]: batch 8 over 8 GPUs)",
+                       "height": H, "width": W, "maxdisp": MAXDISP, "pairs_per_gpu_per_step": 1,
+                       "heads": 3, "parallelism": "pairs sharded over ranks, no collective",
+                       "weights": "reference init (seed 0), BN + heads calibrated"},
+        }
+        if timer is not None:
+            roofs = kernel_rooflines(timer.summary(), args.steps)
+            dominant = max(roofs, key=lambda k: roofs[k]["ms_per_step"])
+            result["roofline"] = dict(roofs[dominant], kernel=dominant)
+            result["rooflines"] = roofs
+            hip_ms = sum(v["ms_per_step"] for v in roofs.values())
+            result["hip_path_ms_per_step"] = round(hip_ms, 3)
+            result["stock_torch_ms_per_step"] = round(ms_per_step - hip_ms, 3)   # 2-D towers
+        if world == 1 and not args.no_cpu_baseline:
+            base, err = cpu_baseline(model, left, right, preds)
+            result["cpu_baseline"] = base
+            result["parity_max_abs_px_vs_cpu"] = err
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

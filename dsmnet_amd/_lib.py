@@ -41,6 +41,7 @@ SIGNATURES = {
     "dsm_conv3d_packed_weight_bytes": (c_size_t, [c_int] * 3),
     "dsm_conv3d_pack_weights": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "dsm_conv3d_fwd": (c_int, [ctypes.POINTER(Conv3dArgs), c_void_p]),
+    "dsm_conv3d_plan": (c_int, [ctypes.POINTER(Conv3dArgs), ctypes.c_char_p, c_int]),
     "dsm_volume_relayout": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
 }
 
@@ -49,6 +50,19 @@ _lib = None
 
 class DsmnetHipError(RuntimeError):
     pass
+
+
+def _bind_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch ships its own libamdhip64.so.7 and this
+    library is linked against the same soname, so the dynamic loader gives both whichever
+    copy was loaded FIRST.  Loading ours before torch would bring in /opt/rocm's runtime,
+    torch would then run on a runtime it was not built with, and launches on torch's
+    streams fail (observed: hipErrorLaunchFailure on the first kernel).  Import torch and
+    map its copy globally before ours."""
+    import torch
+    hip = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        ctypes.CDLL(hip, mode=ctypes.RTLD_GLOBAL)
 
 
 def load():
@@ -60,6 +74,7 @@ def load():
         raise DsmnetHipError(
             "libdsmnet_hip.so not found at %s -- build it with "
             "`python -m dsmnet_amd.csrc.build` (there is no CPU fallback)" % LIB_PATH)
+    _bind_torch_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing

@@ -68,12 +68,43 @@ def _check_conv(conv):
             raise ValueError("transposed 3-D block: stride=2, output_padding=1 only")
 
 
-def run_block(folded, conv, bn, x, residual=None, relu=RELU_NONE):
-    """conv (+ eval-mode BN) (+ cropped skip) (+ ReLU) in one launch."""
-    if bn is not None and bn.training:
+def _crop_add(y, residual):
+    d, h, w = (min(a, b) for a, b in zip(y.shape[2:], residual.shape[2:]))
+    return y[:, :, :d, :h, :w] + residual[:, :, :d, :h, :w]
+
+
+def _run_block_batch_stats(folded, conv, bn, x, residual, relu):
+    """Train-mode forward: the convolution on the HIP kernel, then BatchNorm with batch
+    statistics (running statistics updated as nn.BatchNorm3d does).  Forward only -- the
+    conv3d backward kernels are not in this build, so this path refuses to record
+    autograd history; it exists for BN calibration passes and forward parity."""
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
         raise NotImplementedError(
-            "train-mode BatchNorm in the 3-D trunk needs batch statistics and the conv3d "
-            "backward kernels, which this build does not have yet; call .eval() (inference)")
+            "train-mode 3-D trunk is forward-only in this build (no conv3d backward "
+            "kernels yet): wrap the pass in torch.no_grad(), or call .eval()")
+    packed, _, _ = folded.get(conv, None)
+    bias = None if conv.bias is None else conv.bias.detach()
+    ones = None if bias is None else torch.ones_like(bias)
+    raw = cv.conv3d_block(x, packed, conv.out_channels, ones, bias, None, stride=conv.stride[0],
+                          transposed=isinstance(conv, nn.ConvTranspose3d), relu=RELU_NONE)
+    y = torch.nn.functional.batch_norm(raw, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                                       True, bn.momentum if bn.momentum is not None else 0.1,
+                                       bn.eps)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    if relu == RELU_BEFORE_ADD:
+        y = torch.relu_(y)
+    if residual is not None:
+        y = _crop_add(y, residual)
+    if relu == RELU_AFTER_ADD:
+        y = torch.relu_(y)
+    return y.contiguous(memory_format=torch.channels_last_3d)
+
+
+def run_block(folded, conv, bn, x, residual=None, relu=RELU_NONE):
+    """conv (+ BN) (+ cropped skip) (+ ReLU); one launch in eval mode."""
+    if bn is not None and bn.training:
+        return _run_block_batch_stats(folded, conv, bn, x, residual, relu)
     packed, scale, shift = folded.get(conv, bn)
     return cv.conv3d_block(x, packed, conv.out_channels, scale, shift, residual,
                            stride=conv.stride[0],

@@ -22,6 +22,59 @@ from . import _lib
 _CL3D = torch.channels_last_3d
 
 
+class LaunchTimer(object):
+    """Per-launch timing with HIP events recorded on the launch stream (the stream the
+    kernels are enqueued on -- PyTorch's current stream).  Install with ``set_timer``;
+    bench.py reads ``summary()`` after a synchronise.  Costs two event records per launch."""
+
+    def __init__(self):
+        self.records = []
+
+    def start(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def stop(self, name, start, work):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.append((name, start, ev, work))
+
+    def summary(self):
+        """name -> dict(launches, ms, work); ``work`` is the algorithmic bytes (HBM-bound
+        kernels) or FLOPs (MFMA kernels) summed over the launches.  Call after a sync."""
+        out = {}
+        for name, a, b, work in self.records:
+            e = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0})
+            e["launches"] += 1
+            e["ms"] += a.elapsed_time(b)
+            e["work"] += work
+        return out
+
+
+_timer = None
+
+
+def set_timer(timer):
+    global _timer
+    _timer = timer
+
+
+class _timed(object):
+    """``work``: algorithmic bytes or FLOPs of the launch (SURVEY.md section 8d counting)."""
+
+    def __init__(self, name, work=0.0):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        self.t0 = _timer.start() if _timer is not None else None
+
+    def __exit__(self, *exc):
+        if self.t0 is not None:
+            _timer.stop(self.name() if callable(self.name) else self.name, self.t0, self.work)
+        return False
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -66,7 +119,7 @@ class Corr1dFunction(torch.autograd.Function):
         out = torch.empty((B, D, H, W), device=fL.device, dtype=fL.dtype)
         tmp = torch.empty_like(out) if kernel_size > 1 else None
         lib = _lib.load()
-        with torch.cuda.device(fL.device):
+        with torch.cuda.device(fL.device), _timed("corr1d_fwd_kernel", 4.0 * (2 * B * C * H * W + B * D * H * W)):
             rc = lib.dsm_corr1d_fwd(_p(fL), _p(fR), _p(out), _p(tmp), B, C, H, W, D, stride,
                                     kernel_size, _lib.DSM_F32, _stream())
         _lib.check(rc, "dsm_corr1d_fwd")
@@ -112,7 +165,9 @@ class ConcatVolumeFunction(torch.autograd.Function):
                           memory_format=fmt)
         layout = _lib.DSM_NDHWC if channels_last else _lib.DSM_NCDHW
         lib = _lib.load()
-        with torch.cuda.device(fL.device):
+        with torch.cuda.device(fL.device), \
+                _timed("volume_ndhwc_fwd_kernel" if channels_last else "volume_ncdhw_fwd_kernel",
+                       4.0 * (2 * B * C * H * W + 2 * B * C * D * H * W)):
             rc = lib.dsm_concat_volume_fwd(_p(fL), _p(fR), _p(vol), B, C, H, W, D,
                                            int(mask_left), layout, _lib.DSM_F32, _stream())
         _lib.check(rc, "dsm_concat_volume_fwd")
@@ -164,7 +219,7 @@ class SoftArgminFunction(torch.autograd.Function):
         need_grad = ctx.needs_input_grad[0]
         stats = torch.empty((B, 2, H, W), device=cost.device, dtype=cost.dtype) if need_grad else None
         lib = _lib.load()
-        with torch.cuda.device(cost.device):
+        with torch.cuda.device(cost.device), _timed("soft_argmin_fwd_kernel", 4.0 * B * (Dc * Hc * Wc + H * W)):
             rc = lib.dsm_soft_argmin_fwd(_p(c4), _p(disp), _p(stats), B, Dc, Hc, Wc, D, H, W,
                                          int(negate), int(align_corners), _lib.DSM_F32, _stream())
         _lib.check(rc, "dsm_soft_argmin_fwd")
@@ -274,7 +329,19 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     a.Di, a.Hi, a.Wi = Di, Hi, Wi
     a.Do, a.Ho, a.Wo = Do, Ho, Wo
     a.stride, a.transposed, a.relu = int(stride), int(transposed), int(relu)
-    with torch.cuda.device(x.device):
+    # FLOPs as SURVEY.md section 8d counts them: 2*27*Cin*Cout per output voxel (conv) or
+    # per input voxel (transposed conv)
+    # (Cout = 1 runs on the VALU and is HBM-bound: input read once + output written)
+    vox = B * (Di * Hi * Wi if transposed else Do * Ho * Wo)
+    work = 54.0 * cin * cout * vox if cout > 1 else 4.0 * B * (cin * Di * Hi * Wi + Do * Ho * Wo)
+    with torch.cuda.device(x.device), _timed(lambda: conv3d_plan_name(a), work):
         rc = _lib.load().dsm_conv3d_fwd(ctypes.byref(a), _stream())
     _lib.check(rc, "dsm_conv3d_fwd")
     return y
+
+
+def conv3d_plan_name(args):
+    """Kernel variant ``dsm_conv3d_fwd`` picks for ``args`` (``dsm_conv3d_plan``)."""
+    buf = ctypes.create_string_buffer(96)
+    _lib.check(_lib.load().dsm_conv3d_plan(ctypes.byref(args), buf, 96), "dsm_conv3d_plan")
+    return buf.value.decode()

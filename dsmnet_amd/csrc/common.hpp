@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "../../include/dsmnet_hip.h"
 
 #define DSM_WAVE 64
@@ -12,6 +14,11 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// hipGetLastError() is sticky per thread and is shared with everything else in the
+// process (PyTorch, MIOpen ...): drop whatever an earlier, unrelated call left behind
+// before launching, so that dsm_launch_status() reports only this library's launch.
+static inline void dsm_clear_stale_error() { (void)hipGetLastError(); }
 
 static inline int dsm_launch_status() {
   hipError_t e = hipGetLastError();

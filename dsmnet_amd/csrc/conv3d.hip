@@ -514,19 +514,25 @@ extern "C" int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed, int 
   DSM_REQUIRE(Cin > 0 && Cout > 0, DSM_ERR_ARG);
   DSM_REQUIRE(Cin % 8 == 0 && (Cout == 1 || Cout % 32 == 0), DSM_ERR_UNSUPPORTED);
   const long n = (long)Cin * Cout * 27;
+  dsm_clear_stale_error();
   hipLaunchKernelGGL(pack_weights_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const float*)w_torch, (float*)w_packed, Cin, Cout,
                      transposed);
   return dsm_launch_status();
 }
 
-extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
+namespace {
+// One place decides the kernel variant; dsm_conv3d_fwd launches it, dsm_conv3d_plan names it.
+struct Plan { int kind; int S, NT, TM, CK; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1
+
+int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   DSM_REQUIRE(a && a->x && a->w_packed && a->y, DSM_ERR_ARG);
   DSM_REQUIRE(a->B > 0 && a->Cin > 0 && a->Cout > 0, DSM_ERR_ARG);
   DSM_REQUIRE(a->Di > 0 && a->Hi > 0 && a->Wi > 0 && a->Do > 0 && a->Ho > 0 && a->Wo > 0,
               DSM_ERR_ARG);
   DSM_REQUIRE(a->stride == 1 || a->stride == 2, DSM_ERR_UNSUPPORTED);
   DSM_REQUIRE(!a->transposed || a->stride == 2, DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(a->relu >= 0 && a->relu <= 2, DSM_ERR_ARG);
   DSM_REQUIRE(a->Cin % 16 == 0, DSM_ERR_UNSUPPORTED);
   DSM_REQUIRE(dsm_aligned16(a->x) && dsm_aligned16(a->w_packed) && dsm_aligned16(a->y),
               DSM_ERR_ALIGN);
@@ -537,6 +543,54 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   DSM_REQUIRE(a->Do <= nD && a->Ho <= nH && a->Wo <= nW, DSM_ERR_ARG);
   if (a->residual)
     DSM_REQUIRE(a->Dr >= a->Do && a->Hr >= a->Ho && a->Wr >= a->Wo, DSM_ERR_ARG);
+  if (a->Cout == 1) {
+    if (a->transposed) {
+      DSM_REQUIRE(a->Ho <= 65535 && (long)a->B * a->Do <= 65535, DSM_ERR_UNSUPPORTED);
+      *pl = Plan{3, 2, 0, 0, 0};
+    } else {
+      DSM_REQUIRE(a->stride == 1, DSM_ERR_UNSUPPORTED);
+      *pl = Plan{2, 1, 0, 0, 16};
+    }
+    return DSM_OK;
+  }
+  DSM_REQUIRE(a->Cout == 32 || a->Cout == 64 || a->Cout == 128, DSM_ERR_UNSUPPORTED);
+  const int NT = a->Cout / 32;
+  // Tile height: 8 rows (TM = 2) when that still gives every CU two workgroups of work,
+  // else 4 rows.  Stride 2 stages 8 channels per chunk so that two workgroups fit a CU.
+  if (a->transposed) {
+    const bool big = (long)a->B * a->Di * dsm_cdiv(a->Hi, 8) * dsm_cdiv(a->Wi, 32) * 8 >= 1024;
+    *pl = Plan{1, 2, NT, (big && NT <= 2) ? 2 : 1, 16};
+    return DSM_OK;
+  }
+  const bool big = (long)a->B * a->Do * dsm_cdiv(a->Ho, 8) * dsm_cdiv(a->Wo, 32) >= 1024;
+  if (a->stride == 1) {
+    const int TM = (big && NT <= 2) ? 2 : 1;
+    *pl = Plan{0, 1, NT, TM, (NT == 2 && TM == 2) ? 8 : 16};   // <1,2,2,16> would spill
+  } else {
+    *pl = Plan{0, 2, NT, 1, 8};
+  }
+  return DSM_OK;
+}
+}  // namespace
+
+extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
+  DSM_REQUIRE(buf && len > 0, DSM_ERR_ARG);
+  Plan pl;
+  int rc = make_plan(a, &pl);
+  if (rc != DSM_OK) { buf[0] = 0; return rc; }
+  switch (pl.kind) {
+    case 0: snprintf(buf, len, "conv3d_mfma_kernel<S=%d,NT=%d,TM=%d,CK=%d>", pl.S, pl.NT, pl.TM, pl.CK); break;
+    case 1: snprintf(buf, len, "deconv3d_mfma_kernel<NT=%d,TM=%d,CK=%d>", pl.NT, pl.TM, pl.CK); break;
+    case 2: snprintf(buf, len, "conv3d_cout1_kernel<CK=%d>", pl.CK); break;
+    default: snprintf(buf, len, "deconv3d_cout1_kernel"); break;
+  }
+  return DSM_OK;
+}
+
+extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
+  Plan pl;
+  int rc = make_plan(a, &pl);
+  if (rc != DSM_OK) return rc;
   ConvParams p;
   p.x = (const float*)a->x; p.w = (const float*)a->w_packed; p.scale = a->scale;
   p.shift = a->shift; p.res = (const float*)a->residual; p.y = (float*)a->y;
@@ -545,41 +599,33 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   p.Dr = a->Dr; p.Hr = a->Hr; p.Wr = a->Wr; p.relu = a->relu;
   p.ntx = p.nty = p.ntiles = 0;
   hipStream_t s = (hipStream_t)stream;
-  if (a->Cout == 1) {
-    if (a->transposed) {
-      DSM_REQUIRE(a->Ho <= 65535 && (long)a->B * a->Do <= 65535, DSM_ERR_UNSUPPORTED);
-      dim3 grid(dsm_cdiv(a->Wo, NTHREADS), a->Ho, a->B * a->Do);
-      hipLaunchKernelGGL(deconv3d_cout1_kernel, grid, dim3(NTHREADS), 0, s, p);
-      return dsm_launch_status();
-    }
-    DSM_REQUIRE(a->stride == 1, DSM_ERR_UNSUPPORTED);
+  dsm_clear_stale_error();
+  if (pl.kind == 3) {
+    dim3 grid(dsm_cdiv(a->Wo, NTHREADS), a->Ho, a->B * a->Do);
+    hipLaunchKernelGGL(deconv3d_cout1_kernel, grid, dim3(NTHREADS), 0, s, p);
+    return dsm_launch_status();
+  }
+  if (pl.kind == 2) {
     p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, 8);
     p.ntiles = p.B * p.Do * p.nty * p.ntx;
     const size_t lds = (size_t)3 * 10 * 4 * 34 * 16;
     return launch_tiles(conv3d_cout1_kernel<16>, p, lds, s, 2048);
   }
-  DSM_REQUIRE(a->Cout == 32 || a->Cout == 64 || a->Cout == 128, DSM_ERR_UNSUPPORTED);
-  // Tile height: 8 rows (TM = 2) when that still gives every CU two workgroups of
-  // work, else 4 rows.  Stride 2 stages 8 channels per chunk to fit two workgroups.
-  if (a->transposed) {
-    const bool big = (long)a->B * a->Di * dsm_cdiv(a->Hi, 8) * dsm_cdiv(a->Wi, 32) * 8 >= 1024;
-    switch (a->Cout) {
-      case 32:  return big ? run_deconv<1, 2, 16>(p, s) : run_deconv<1, 1, 16>(p, s);
-      case 64:  return big ? run_deconv<2, 2, 16>(p, s) : run_deconv<2, 1, 16>(p, s);
-      default:  return run_deconv<4, 1, 16>(p, s);
-    }
-  }
-  const bool big = (long)a->B * a->Do * dsm_cdiv(a->Ho, 8) * dsm_cdiv(a->Wo, 32) >= 1024;
-  if (a->stride == 1) {
-    switch (a->Cout) {
-      case 32:  return big ? run_conv<1, 1, 2, 16>(p, s) : run_conv<1, 1, 1, 16>(p, s);
-      case 64:  return big ? run_conv<1, 2, 2, 8>(p, s) : run_conv<1, 2, 1, 16>(p, s);
-      default:  return run_conv<1, 4, 1, 16>(p, s);
-    }
-  }
-  switch (a->Cout) {
-    case 32:  return run_conv<2, 1, 1, 8>(p, s);
-    case 64:  return run_conv<2, 2, 1, 8>(p, s);
-    default:  return run_conv<2, 4, 1, 8>(p, s);
-  }
+#define DSM_CASE(KIND, S_, NT_, TM_, CK_, CALL) \
+  if (pl.kind == KIND && pl.S == S_ && pl.NT == NT_ && pl.TM == TM_ && pl.CK == CK_) return CALL
+  DSM_CASE(1, 2, 1, 2, 16, (run_deconv<1, 2, 16>(p, s)));
+  DSM_CASE(1, 2, 1, 1, 16, (run_deconv<1, 1, 16>(p, s)));
+  DSM_CASE(1, 2, 2, 2, 16, (run_deconv<2, 2, 16>(p, s)));
+  DSM_CASE(1, 2, 2, 1, 16, (run_deconv<2, 1, 16>(p, s)));
+  DSM_CASE(1, 2, 4, 1, 16, (run_deconv<4, 1, 16>(p, s)));
+  DSM_CASE(0, 1, 1, 2, 16, (run_conv<1, 1, 2, 16>(p, s)));
+  DSM_CASE(0, 1, 1, 1, 16, (run_conv<1, 1, 1, 16>(p, s)));
+  DSM_CASE(0, 1, 2, 2, 8, (run_conv<1, 2, 2, 8>(p, s)));
+  DSM_CASE(0, 1, 2, 1, 16, (run_conv<1, 2, 1, 16>(p, s)));
+  DSM_CASE(0, 1, 4, 1, 16, (run_conv<1, 4, 1, 16>(p, s)));
+  DSM_CASE(0, 2, 1, 1, 8, (run_conv<2, 1, 1, 8>(p, s)));
+  DSM_CASE(0, 2, 2, 1, 8, (run_conv<2, 2, 1, 8>(p, s)));
+  DSM_CASE(0, 2, 4, 1, 8, (run_conv<2, 4, 1, 8>(p, s)));
+#undef DSM_CASE
+  return DSM_ERR_UNSUPPORTED;
 }

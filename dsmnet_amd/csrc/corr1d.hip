@@ -189,6 +189,7 @@ extern "C" int dsm_corr1d_fwd(const void* fL, const void* fR, void* out, void* t
   if (rc != DSM_OK) return rc;
   DSM_REQUIRE(ksize == 1 || tmp, DSM_ERR_ARG);
   hipStream_t s = (hipStream_t)stream;
+  dsm_clear_stale_error();
   float* raw = (float*)(ksize > 1 ? tmp : out);
   const int ndg = (D + DB - 1) / DB;
   const int vec = (W % 4 == 0) && dsm_aligned16(fL) && dsm_aligned16(fR) && dsm_aligned16(raw);
@@ -223,6 +224,7 @@ extern "C" int dsm_corr1d_bwd(const void* grad_out, const void* fL, const void* 
   DSM_REQUIRE(dfL && dfR, DSM_ERR_ARG);
   DSM_REQUIRE(ksize == 1 || tmp, DSM_ERR_ARG);
   hipStream_t s = (hipStream_t)stream;
+  dsm_clear_stale_error();
   const float* g = (const float*)grad_out;
   if (ksize > 1) {
     dim3 grid(dsm_cdiv(W, 256), H, B * D);

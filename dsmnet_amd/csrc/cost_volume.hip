@@ -214,6 +214,7 @@ extern "C" int dsm_concat_volume_fwd(const void* fL, const void* fR, void* vol, 
   int rc = check_volume_args(fL, fR, vol, B, C, H, W, D, layout, dtype);
   if (rc != DSM_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
+  dsm_clear_stale_error();
   const float* l = (const float*)fL;
   const float* r = (const float*)fR;
   float* v = (float*)vol;
@@ -223,9 +224,10 @@ extern "C" int dsm_concat_volume_fwd(const void* fL, const void* fR, void* vol, 
     constexpr int TX = 32;
     const size_t lds = (size_t)(TX + TX + D - 1) * (C + 4) * sizeof(float);
     DSM_REQUIRE(lds <= 160 * 1024, DSM_ERR_UNSUPPORTED);
-    if (lds > 64 * 1024)
-      hipFuncSetAttribute((const void*)volume_ndhwc_fwd_kernel<TX>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)volume_ndhwc_fwd_kernel<TX>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return DSM_ERR_LAUNCH;
     dim3 grid(dsm_cdiv(W, TX), H, B);
     hipLaunchKernelGGL(volume_ndhwc_fwd_kernel<TX>, grid, dim3(256), lds, s, l, r, v, C, H, W, D,
                        mask_left);
@@ -251,6 +253,7 @@ extern "C" int dsm_concat_volume_bwd(const void* gvol, void* dfL, void* dfR, int
   int rc = check_volume_args(gvol, dfL, dfR, B, C, H, W, D, layout, dtype);
   if (rc != DSM_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
+  dsm_clear_stale_error();
   if (layout == DSM_NDHWC) {
     DSM_REQUIRE(C % 4 == 0, DSM_ERR_UNSUPPORTED);
     DSM_REQUIRE(dsm_aligned16(gvol), DSM_ERR_ALIGN);
@@ -276,6 +279,7 @@ extern "C" int dsm_volume_relayout(const void* src, void* dst, int B, int C, int
   const long S = (long)D * H * W;
   DSM_REQUIRE(B <= 65535 && dsm_cdiv(C, 64) <= 65535, DSM_ERR_UNSUPPORTED);
   dim3 grid((unsigned)dsm_cdiv(S, 64), dsm_cdiv(C, 64), B);
+  dsm_clear_stale_error();
   hipLaunchKernelGGL(relayout_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src,
                      (float*)dst, C, S, to_ndhwc);
   return dsm_launch_status();

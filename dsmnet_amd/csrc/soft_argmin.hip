@@ -244,6 +244,7 @@ extern "C" int dsm_soft_argmin_fwd(const void* cost, void* disp, void* stats, in
   const int px_per_block = 4 * (DSM_WAVE / ds);
   dim3 grid(dsm_cdiv(W, px_per_block), H, B), block(256);
   hipStream_t s = (hipStream_t)stream;
+  dsm_clear_stale_error();
 #define SA_LAUNCH(UP, DS) hipLaunchKernelGGL((soft_argmin_fwd_kernel<UP, DS>), grid, block, 0, s, p)
   if (up) { if (ds == 4) SA_LAUNCH(true, 4); else if (ds == 2) SA_LAUNCH(true, 2); else SA_LAUNCH(true, 1); }
   else    { if (ds == 4) SA_LAUNCH(false, 4); else if (ds == 2) SA_LAUNCH(false, 2); else SA_LAUNCH(false, 1); }
@@ -267,6 +268,7 @@ extern "C" int dsm_soft_argmin_bwd(const void* cost, const void* disp, const voi
   p.sign = negate ? -1.f : 1.f; p.align = align_corners;
   const bool up = !(Dc == D && Hc == H && Wc == W);
   hipStream_t s = (hipStream_t)stream;
+  dsm_clear_stale_error();
   dim3 grid(dsm_cdiv(W, 256), H, B), block(256);
   if (up) {
     if (hipMemsetAsync(dcost, 0, (size_t)B * Dc * Hc * Wc * sizeof(float), s) != hipSuccess)

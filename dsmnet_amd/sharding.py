@@ -1,0 +1,90 @@
+"""Multi-GPU use of the cost-volume path: one process per GPU, pairs sharded.
+
+The reference is single-process, single-device (`stereo.py:24,32-34`; its only trace of data
+parallelism is a commented-out DistributedDataParallel line).  A stereo pair's forward is
+independent of every other pair's, so inference shards pairs across ranks with **no collective
+on the data path**; the only exchange the path ever needs is the optional training-time
+gradient all-reduce (PSMNet 5.22 M parameters = 20.9 MB fp32 per step, a
+~0.24 ms ring over xGMI -- negligible next to the step, so one flat bucket, no overlap logic).
+
+`torch.distributed` with backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the process group from torchrun's environment (RANK, WORLD_SIZE, MASTER_*).
+    Returns (rank, world_size, local_rank).  Single-process runs need no group."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local_rank
+
+
+def pair_indices(num_pairs, rank, world):
+    """Indices of the pairs rank ``rank`` owns: pair i -> rank i mod world.
+    Every pair is owned exactly once; loads differ by at most one pair."""
+    if not (0 <= rank < world):
+        raise ValueError("rank %d outside world of %d" % (rank, world))
+    return list(range(rank, num_pairs, world))
+
+
+def shard_batch(left, right, rank, world):
+    """The slice of a (B,3,H,W) batch this rank processes (interleaved, like pair_indices)."""
+    if left.shape != right.shape:
+        raise ValueError("left/right batch shapes differ")
+    idx = pair_indices(left.shape[0], rank, world)
+    return left[idx], right[idx], idx
+
+
+def gather_disparities(local, idx, num_pairs, world):
+    """Optional: reassemble the per-pair outputs on every rank (evaluation convenience; not
+    used by the benchmark).  ``local``: (len(idx), ...) tensor."""
+    if world == 1:
+        return local
+    counts = [len(range(r, num_pairs, world)) for r in range(world)]
+    pad = max(counts)
+    buf = local.new_zeros((pad,) + tuple(local.shape[1:]))
+    buf[: local.shape[0]] = local
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    out = local.new_empty((num_pairs,) + tuple(local.shape[1:]))
+    for r in range(world):
+        out[r:num_pairs:world] = parts[r][: counts[r]]
+    return out
+
+
+def allreduce_gradients(parameters, world=None):
+    """Average gradients across ranks with ONE flat all-reduce (sum, then / world).
+    Parameters without a gradient contribute zeros so that every rank reduces the same
+    buffer.  Returns the number of elements reduced."""
+    world = dist.get_world_size() if world is None else world
+    params = [p for p in parameters if p.requires_grad]
+    if world == 1 or not params:
+        return 0
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                      for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(world)
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off: off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n
+    return off

@@ -148,6 +148,11 @@ int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed,
 
 int dsm_conv3d_fwd(const dsm_conv3d_args* args, dsm_stream_t stream);
 
+/* Name of the kernel variant dsm_conv3d_fwd would launch for `args` (tile shape and
+ * channel chunk are chosen per layer) -- written NUL-terminated into buf[len];
+ * used by bench.py to attribute per-launch timings.  No launch, no device access. */
+int dsm_conv3d_plan(const dsm_conv3d_args* args, char* buf, int len);
+
 /* NCDHW <-> NDHWC repack of an fp32 volume (used at the boundary with stock
  * torch modules that want contiguous NCDHW). to_ndhwc = 1: src NCDHW. */
 int dsm_volume_relayout(const void* src, void* dst, int B, int C, int D, int H, int W,

@@ -53,9 +53,80 @@ def test_psmnet_end_to_end_256x512(hip_lib, golden_e2e):
         assert maxerr(p, r) <= DISP_TOL, nm                      # vs the oracle, every pixel
 
 
-def test_psmnet_rejects_train_mode(hip_lib):
+def test_psmnet_train_mode_forward_vs_golden(hip_lib, golden_blocks):
+    """Train-mode BN (batch statistics) forward: HIP convolution + BatchNorm3d with batch
+    stats, against the reference's train-mode goldens; recording autograd is refused."""
+    meta = golden_blocks.meta["blocks"]
+    sd = randomise_bn(OM.init_state("psmnet", meta["psm_state_seed"]), meta["psm_bn_seed"])
     from dsmnet_amd.models import model_create_by_name
-    m = model_create_by_name("psmnet", 192).cuda().train()
-    x = torch.zeros(1, 64, 4, 8, 32, device="cuda")
+    m = model_create_by_name("psmnet", 192)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    x64 = seeded(meta["x64_seed"], *meta["x64_shape"]).cuda()
+    x32 = seeded(meta["x32_seed"], *meta["x32_shape"]).cuda()
+    with torch.no_grad():
+        r0 = m.dres0(x64)
+        o1, pre1, post1 = m.dres2(x32, None, None)
+    golden_blocks.compare("block3d.psm.train.dres0", r0, 5e-4)
+    golden_blocks.compare("block3d.psm.train.hg1.out", o1, 5e-4)
+    golden_blocks.compare("block3d.psm.train.hg1.post", post1, 5e-4)
+    assert int(m.dres0[0][1].num_batches_tracked) == 1
     with pytest.raises(NotImplementedError):
-        m.dres0(x)
+        m.dres0(x64)                                   # grad mode on: refused
+
+
+def test_gcnet_end_to_end_64x128(hip_lib, golden_e2e):
+    """GCNet, D=192 (96 planes at 1/2), 64x128: left-unmasked volume, relu-before-skip
+    epilogues, 128-channel levels, the 32->1 transposed head and the negated soft-argmin."""
+    sd, cfg = golden_state(golden_e2e, "gcnet")
+    imL, imR = images(cfg["image_seed"], *cfg["hw"])
+    m = load("gcnet", sd)
+    with torch.no_grad():
+        scales, (disp,) = m(imL.cuda(), imR.cuda())
+        ref = OM.forward("gcnet", sd, imL, imR)
+    assert scales == [0] and disp.shape == (1, 1, 64, 128)
+    golden_e2e.compare("e2e.gcnet.disp", disp, DISP_TOL)
+    assert maxerr(disp, ref) <= DISP_TOL
+
+
+def test_dispnetcorr_end_to_end_256x512(hip_lib, golden_e2e):
+    """DispNetC (BASELINE config #1 shape, on the GPU): HIP Corr1d inside the stock 2-D net;
+    all seven outputs.  Outputs are O(1) disparities; 2e-3 covers MIOpen-vs-oneDNN fp32
+    summation order through 26 layers."""
+    sd, cfg = golden_state(golden_e2e, "dispnetcorr")
+    imL, imR = images(cfg["image_seed"], *cfg["hw"])
+    m = load("dispnetcorr", sd)
+    with torch.no_grad():
+        scales, outs = m(imL.cuda(), imR.cuda())
+    assert scales == list(range(7)) and len(outs) == 7
+    for i, o in enumerate(outs):
+        golden_e2e.compare("e2e.dispnetcorr.pr%d" % i, o, 2e-3)
+
+
+def test_iresnet_end_to_end_256x512(hip_lib, golden_e2e):
+    """iResNet: both correlations (D=81; kernel 3 / stride 2 / D=41) on the HIP path."""
+    sd, cfg = golden_state(golden_e2e, "iresnet")
+    imL, imR = images(cfg["image_seed"], *cfg["hw"])
+    m = load("iresnet", sd)
+    with torch.no_grad():
+        torch.manual_seed(cfg["torch_seed"])       # imwrap's random epsilon
+        scales, outs = m(imL.cuda(), imR.cuda())
+    assert len(outs) == 10 and scales[:3] == [0, 1, 2]
+    for i, o in enumerate(outs):
+        golden_e2e.compare("e2e.iresnet.out%d" % i, o, 2e-3)
+
+
+def test_psmnet_540x960_crop_add(hip_lib):
+    """The shape where myadd_3d really crops: 135 -> 68 -> 34 -> 68 -> 136
+    vs 135.  Trunk only (volume from random features), against the oracle trunk."""
+    from dsmnet_amd import costvolume as cv
+    sd = randomise_bn(OM.init_state("psmnet", 0), 41)
+    m = load("psmnet", sd)
+    fl, fr = seeded(71, 1, 32, 17, 31) , seeded(72, 1, 32, 17, 31)     # odd sizes at every level
+    with torch.no_grad():
+        got = m.regularise(cv.concat_volume(fl.cuda(), fr.cuda(), 12, True))
+        from oracle import ops as OO
+        ref = OM.psmnet_trunk(OM.Net(sd), OO.concat_volume(fl, fr, 12, True))
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape == (1, 1, 12, 17, 31)
+        assert maxerr(g, r) <= 5e-4 * max(1.0, r.abs().max().item())
