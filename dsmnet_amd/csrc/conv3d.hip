@@ -34,8 +34,20 @@
 // K order inside an 8-channel group: MFMA step j multiplies channels
 // {8g + j (lanes 0-31), 8g + 4 + j (lanes 32-63)}; A and B fragments agree on it.
 #include "common.hpp"
+#include <type_traits>
 
 namespace {
+
+// Compile-time loop: f(integral_constant<int, I>) for I in [I0, N).  Used where an index must
+// be a constant expression so that accumulator arrays stay in registers (a runtime-indexed
+// ext-vector array goes to scratch).
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 constexpr int NTHREADS = 256;
 
@@ -72,6 +84,48 @@ __device__ __forceinline__ int first_tile(int ntiles, int& step, int& end) {
   end = min(ntiles, lo + per);
   step = G >> 3;
   return lo + slot;
+}
+
+// Epilogue of one 32x32 accumulator tile: rows = 32 consecutive x of one output row (stride
+// XS voxels in memory: 1 for convolutions, 2 for a transposed-conv parity class), columns =
+// 32 output channels on the lanes.  y = acc*sc + sh (ReLU?) (+ skip) (ReLU?).
+// Interior tiles (wave-uniform test) take a branch-free path with all 16 skip loads in flight
+// and compile-time address offsets; edge tiles fall back to per-element guards.
+template <int COUT, int XS>
+__device__ __forceinline__ void store_tile(const f32x16& acc, float sc, float sh, int relu,
+                                           float* __restrict__ yrow, const float* __restrict__ rrow,
+                                           int h, int xbase, int xlimit) {
+  // yrow / rrow point at voxel (row start, x = xbase-th output column), channel co of this lane
+  constexpr int VS = COUT * XS;                       // floats between consecutive tile rows
+  float* yp = yrow + (long)(4 * h) * VS;
+  const float* rp = rrow ? rrow + (long)(4 * h) * VS : nullptr;
+  if (xbase + 31 * XS < xlimit) {                     // whole tile inside the row
+    float r[16];
+    if (rp) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r[i] = rp[((i & 3) + 8 * (i >> 2)) * VS];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = acc[i] * sc + sh;
+      if (relu == 2) v = fmaxf(v, 0.f);
+      if (rp) v += r[i];
+      if (relu == 1) v = fmaxf(v, 0.f);
+      yp[((i & 3) + 8 * (i >> 2)) * VS] = v;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (xbase + row * XS < xlimit) {
+        float v = acc[i] * sc + sh;
+        if (relu == 2) v = fmaxf(v, 0.f);
+        if (rp) v += rp[((i & 3) + 8 * (i >> 2)) * VS];
+        if (relu == 1) v = fmaxf(v, 0.f);
+        yp[((i & 3) + 8 * (i >> 2)) * VS] = v;
+      }
+    }
+  }
 }
 
 // ----------------------------------------------------------------------------
@@ -154,44 +208,59 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
     }
-    // ---- multiply: 27 taps x NG groups, B fragments three items ahead ----------
+    // ---- multiply: 27 taps x NG groups ------------------------------------------------
+    // Software pipeline, pinned with sched_barrier(0) (left alone, hipcc sinks the loads
+    // next to their first use and waits vmcnt(0) per item): B fragments are requested
+    // AHEAD-1 items before use (>= 1.5k cycles of MFMA cover the L2 round trip), the next
+    // item's A fragments one item before use; each MFMA cluster runs on operands that were
+    // requested at least one full cluster earlier.
     constexpr int NITEM = 27 * NG;
-    constexpr int AHEAD = 3;
+    constexpr int AHEAD = (TM * NT >= 4) ? 3 : ((TM * NT >= 2) ? 4 : 6);
     f32x4 bq[AHEAD][NT];
+    f32x4 abuf[2][TM];
     const f32x4* wbase = wp + (long)ck * NG * 27 * NT * 64 + lane;   // [g][tap][nt][lane]
-    auto bload = [&](int item, f32x4 (&dst)[NT]) {
-      const int tap = item / NG, gi = item % NG;
+    auto bload = [&](auto ic) {
+      constexpr int item = decltype(ic)::value;
+      constexpr int tap = item / NG, gi = item % NG;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) dst[n] = wbase[((gi * 27 + tap) * NT + n) * 64];
+      for (int n = 0; n < NT; ++n) bq[item % AHEAD][n] = wbase[((gi * 27 + tap) * NT + n) * 64];
     };
-#pragma unroll
-    for (int i = 0; i < AHEAD - 1; ++i) bload(i, bq[i]);
-#pragma unroll
-    for (int item = 0; item < NITEM; ++item) {
-      if (item + AHEAD - 1 < NITEM) bload(item + AHEAD - 1, bq[(item + AHEAD - 1) % AHEAD]);
-      const int tap = item / NG, gi = item % NG;
-      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-      const int xoff = (S == 1) ? dx : ((dx & 1) * G::XE + (dx >> 1));
-      f32x4 a[TM];
+    auto aload = [&](auto ic) {
+      constexpr int item = decltype(ic)::value;
+      constexpr int tap = item / NG, gi = item % NG;
+      constexpr int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      constexpr int xoff = (S == 1) ? dx : ((dx & 1) * G::XE + (dx >> 1));
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
         const int yy = (wave * TM + m) * S + dy;
-        a[m] = tile[(dz * IY + yy) * ROW + (2 * gi) * XP + xoff + lane_el];
+        abuf[item & 1][m] = tile[(dz * IY + yy) * ROW + (2 * gi) * XP + xoff + lane_el];
       }
+    };
+    static_for<0, AHEAD - 1>(bload);
+    aload(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, NITEM>([&](auto ic) {
+      constexpr int item = decltype(ic)::value;
+      if constexpr (item + AHEAD - 1 < NITEM) bload(std::integral_constant<int, item + AHEAD - 1>{});
+      if constexpr (item + 1 < NITEM) aload(std::integral_constant<int, item + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
+          const f32x4 aa = abuf[item & 1][m];
           const f32x4 bb = bq[item % AHEAD][n];
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, bb.x, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, bb.y, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bb.z, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bb.w, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.x, bb.x, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.y, bb.y, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.z, bb.z, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.w, bb.w, acc[m][n], 0, 0, 0);
         }
-    }
+      __builtin_amdgcn_sched_barrier(0);
+    });
     // ---- epilogue after the last chunk of a tile --------------------------------
     if (ck == nch - 1) {
       decode(t);
+      constexpr int COUT = 32 * NT;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int co = n * 32 + r;
@@ -200,18 +269,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
           const int yo = ty0 + wave * TM + m;
-          if (yo >= p.Ho) continue;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int xo = tx0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (xo >= p.Wo) continue;
-            float v = acc[m][n][i] * sc + sh;
-            if (p.relu == 2) v = fmaxf(v, 0.f);
-            if (p.res)
-              v += p.res[((((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo) * p.Cout + co];
-            if (p.relu == 1) v = fmaxf(v, 0.f);
-            p.y[((((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo) * p.Cout + co] = v;
-          }
+          if (yo >= p.Ho) continue;                         // wave-uniform
+          float* yrow = p.y + ((((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + tx0) * COUT + co;
+          const float* rrow = p.res
+              ? p.res + ((((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + tx0) * COUT + co : nullptr;
+          store_tile<COUT, 1>(acc[m][n], sc, sh, p.relu, yrow, rrow, h, tx0, p.Wo);
         }
       }
     }
@@ -224,12 +286,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
 // ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1), Cout = 32*NT.
 //   out[o] += in[i] * w[k],  o = 2i - 1 + k   per dimension, so an output of parity
 //   0 (o = 2m) has one tap (k=1, i=m) and of parity 1 (o = 2m+1) two taps
-//   (k=2, i=m) and (k=0, i=m+1).  A work item is (input-grid tile, parity class):
-//   a dense little convolution with 1..8 taps on the input grid.
+//   (k=2, i=m) and (k=0, i=m+1): 8 parity classes with 1..8 taps, 27 in all.
+// A work item is (input-grid tile of 4 rows x 32 columns at depth m, z-parity pz).  Its four
+// (py,px) classes are accumulated together: an A fragment read at input offset (iy,ix)
+// feeds every class that has a tap there (4, 2, 2, 1 classes), so the tile is staged once
+// per channel chunk for 9*(pz+1) tap-steps.  The step schedule is static; B fragments run
+// three steps ahead; the next item's chunk is prefetched into registers while this one is
+// multiplied -- the same pipeline as conv3d_mfma_kernel.
 // ----------------------------------------------------------------------------
-template <int NT, int TM, int CK>
+// Step schedule, ordered (input offset, channel group, class) so that one A fragment
+// serves consecutive steps.  Offsets (iy,ix): (0,0) feeds classes {0,1,2,3}, (0,1) feeds
+// {1,3}, (1,0) feeds {2,3}, (1,1) feeds {3}; class = py*2 + px.
+struct DeconvStep { int iy, ix, gi, cls, fresh; };
+__host__ __device__ constexpr DeconvStep deconv_step(int s, int NG);
+// number of fresh (A-fragment-loading) steps before global step S2 (steps repeat per iz)
+__host__ __device__ constexpr int deconv_fresh_before(int S2, int NG);
+__host__ __device__ constexpr int deconv_aslot(int S2, int NG);
+__host__ __device__ constexpr int deconv_next_fresh(int S2, int NG);
+__host__ __device__ constexpr DeconvStep deconv_step(int s, int NG) {
+  constexpr int n_off[4] = {4, 2, 2, 1};
+  constexpr int cls_of[4][4] = {{0, 1, 2, 3}, {1, 3, 0, 0}, {2, 3, 0, 0}, {3, 0, 0, 0}};
+  int o = 0, base = 0;
+  while (s >= base + n_off[o] * NG) { base += n_off[o] * NG; ++o; }
+  const int rel = s - base;
+  return DeconvStep{o >> 1, o & 1, rel / n_off[o], cls_of[o][rel % n_off[o]],
+                    (rel % n_off[o]) == 0};
+}
+__host__ __device__ constexpr int deconv_fresh_before(int S2, int NG) {
+  int n = 0;
+  for (int i = 0; i < S2; ++i) n += deconv_step(i % (9 * NG), NG).fresh;
+  return n;
+}
+// LDS-read double buffer: the A fragment of step S2 lives in slot (index of its fresh step) & 1
+__host__ __device__ constexpr int deconv_aslot(int S2, int NG) {
+  return (deconv_fresh_before(S2 + 1, NG) - 1) & 1;
+}
+__host__ __device__ constexpr int deconv_next_fresh(int S2, int NG) {
+  int i = S2 + 1;
+  while (i < 2 * 9 * NG && !deconv_step(i % (9 * NG), NG).fresh) ++i;
+  return i;
+}
+
+template <int NT, int CK>
 __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p) {
-  constexpr int TY = 4 * TM;
+  constexpr int TY = 4;
   constexpr int IZ = 2, IY = TY + 1, IX = 33, XP = 34;
   constexpr int NQ = CK / 4, NG = CK / 8;
   constexpr int NE = IZ * IY * IX * NQ;
@@ -243,90 +343,152 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
   const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(p.w);
   const int lane_el = h * XP + r;
 
-  for (int item = blockIdx.x; item < p.ntiles; item += gridDim.x) {
-    const int cls = item & 7;
-    int id = item >> 3;
-    const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
-    const int ty0 = (id % p.nty) * TY; id /= p.nty;
-    const int tz = id % p.Di; const int tb = id / p.Di;
-    const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
-    const int zo = 2 * tz + pz;
-    if (zo >= p.Do) continue;                       // cropped away (uniform per workgroup)
+  int step, end;
+  int t = first_tile(p.ntiles, step, end);
+  if (t >= end) return;
 
-    f32x16 acc[TM][NT];
+  f32x4 pf[NPF];
+  auto prefetch = [&](int id, int ck) {
+    id >>= 1;                                            // drop the z-parity bit
+    const int xb = (id % p.ntx) * 32; id /= p.ntx;
+    const int yb = (id % p.nty) * TY; id /= p.nty;
+    const int zb = id % p.Di; const int b = id / p.Di;
 #pragma unroll
-    for (int m = 0; m < TM; ++m)
-#pragma unroll
-      for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
-
-    for (int ck = 0; ck < nch; ++ck) {
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < NPF; ++k) {
-        const int e = tid + k * NTHREADS;
-        const int q = e % NQ, v = e / NQ;
-        const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
-        const int zi = tz + zz, yi = ty0 + yy, xi = tx0 + xx;
-        f32x4 val = {0.f, 0.f, 0.f, 0.f};
-        if (e < NE && zi < p.Di && yi < p.Hi && xi < p.Wi)
-          val = *reinterpret_cast<const f32x4*>(
-              p.x + ((((long)tb * p.Di + zi) * p.Hi + yi) * p.Wi + xi) * p.Cin + ck * CK + q * 4);
-        if (e < NE) tile[(zz * IY + yy) * ROW + q * XP + xx] = val;
-      }
-      __syncthreads();
-      for (int iz = 0; iz <= pz; ++iz)
-        for (int iy = 0; iy <= py; ++iy)
-          for (int ix = 0; ix <= px; ++ix) {
-            // parity 0: (k=1, di=0); parity 1: first (k=2, di=0) then (k=0, di=1)
-            const int kz = pz ? (iz ? 0 : 2) : 1, ky = py ? (iy ? 0 : 2) : 1,
-                      kx = px ? (ix ? 0 : 2) : 1;
-            const int tap = (kz * 3 + ky) * 3 + kx;
-#pragma unroll
-            for (int gi = 0; gi < NG; ++gi) {
-              f32x4 bb[NT];
-#pragma unroll
-              for (int n = 0; n < NT; ++n)
-                bb[n] = wp[((((long)(ck * NG + gi)) * 27 + tap) * NT + n) * 64 + lane];
-#pragma unroll
-              for (int m = 0; m < TM; ++m) {
-                const int yy = wave * TM + m + iy;
-                const f32x4 a = tile[(iz * IY + yy) * ROW + (2 * gi) * XP + ix + lane_el];
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                  acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb[n].x, acc[m][n], 0, 0, 0);
-                  acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb[n].y, acc[m][n], 0, 0, 0);
-                  acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bb[n].z, acc[m][n], 0, 0, 0);
-                  acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bb[n].w, acc[m][n], 0, 0, 0);
-                }
-              }
-            }
-          }
+    for (int k = 0; k < NPF; ++k) {
+      const int e = tid + k * NTHREADS;
+      const int q = e % NQ, v = e / NQ;
+      const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
+      const int zi = zb + zz, yi = yb + yy, xi = xb + xx;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (e < NE && zi < p.Di && yi < p.Hi && xi < p.Wi)
+        val = *reinterpret_cast<const f32x4*>(
+            p.x + ((((long)b * p.Di + zi) * p.Hi + yi) * p.Wi + xi) * p.Cin + ck * CK + q * 4);
+      pf[k] = val;
     }
+  };
+  auto commit = [&]() {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int co = n * 32 + r;
-      const float sc = p.scale ? p.scale[co] : 1.f;
-      const float sh = p.shift ? p.shift[co] : 0.f;
+    for (int k = 0; k < NPF; ++k) {
+      const int e = tid + k * NTHREADS;
+      const int q = e % NQ, v = e / NQ;
+      const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
+      if (e < NE) tile[(zz * IY + yy) * ROW + q * XP + xx] = pf[k];
+    }
+  };
+
+  f32x16 acc[4][NT];                                     // class = py*2 + px
+  int ck = 0;
+  prefetch(t, 0);
+  while (true) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    int nt_ = t, nck = ck + 1;
+    if (nck == nch) { nck = 0; nt_ = t + step; }
+    if (nt_ < end) prefetch(nt_, nck);
+    if (ck == 0) {
 #pragma unroll
-      for (int m = 0; m < TM; ++m) {
-        const int yo = 2 * (ty0 + wave * TM + m) + py;
-        if (ty0 + wave * TM + m >= p.Hi || yo >= p.Ho) continue;
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int xm = tx0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const int xo = 2 * xm + px;
-          if (xm >= p.Wi || xo >= p.Wo) continue;
-          float v = acc[m][n][i] * sc + sh;
-          if (p.relu == 2) v = fmaxf(v, 0.f);
-          if (p.res)
-            v += p.res[((((long)tb * p.Dr + zo) * p.Hr + yo) * p.Wr + xo) * p.Cout + co];
-          if (p.relu == 1) v = fmaxf(v, 0.f);
-          p.y[((((long)tb * p.Do + zo) * p.Ho + yo) * p.Wo + xo) * p.Cout + co] = v;
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[c][n][i] = 0.f;
+    }
+    const int pz = t & 1;
+    const f32x4* wbase = wp + (long)ck * NG * 27 * NT * 64 + lane;
+    {
+      // Both z taps of a z-odd item (iz = 0, 1) run as one pipelined sequence of
+      // 2*NSTEP steps; a z-even item stops after NSTEP (wave-uniform branch).  Same pinned
+      // software pipeline as the forward convolution.
+      constexpr int NSTEP = 9 * NG;
+      constexpr int AHEAD = (NT >= 2) ? 3 : 6;
+      const int kz0 = pz ? 2 : 1;                        // iz = 0; iz = 1 (pz only) uses kz = 0
+      f32x4 bq[AHEAD][NT];
+      f32x4 abuf[2];
+      auto bload = [&](auto sc) {
+        constexpr int S2 = decltype(sc)::value;
+        constexpr int iz = S2 / NSTEP, s = S2 % NSTEP;
+        constexpr DeconvStep st = deconv_step(s, NG);
+        constexpr int py = st.cls >> 1, px = st.cls & 1;
+        constexpr int ky = py ? (st.iy ? 0 : 2) : 1, kx = px ? (st.ix ? 0 : 2) : 1;
+        const int tap = ((iz ? 0 : kz0) * 3 + ky) * 3 + kx;
+        constexpr int ring = S2 % AHEAD;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bq[ring][n] = wbase[((st.gi * 27 + tap) * NT + n) * 64];
+      };
+      auto aload = [&](auto sc) {                       // slot = parity of the fresh-read count
+        constexpr int S2 = decltype(sc)::value;
+        constexpr int iz = S2 / NSTEP, s = S2 % NSTEP;
+        constexpr DeconvStep st = deconv_step(s, NG);
+        constexpr int slot = deconv_aslot(S2, NG);
+        abuf[slot] = tile[(iz * IY + wave + st.iy) * ROW + (2 * st.gi) * XP + st.ix + lane_el];
+      };
+      auto body = [&](auto sc) {
+        constexpr int S2 = decltype(sc)::value;
+        constexpr int s = S2 % NSTEP;
+        constexpr DeconvStep st = deconv_step(s, NG);
+        constexpr int c = st.cls;
+        // prefetch: B for step S2+AHEAD-1, A for the next fresh step (one fresh step ahead)
+        if constexpr (S2 + AHEAD - 1 < 2 * NSTEP) {
+          if (S2 + AHEAD - 1 < NSTEP || pz) bload(std::integral_constant<int, S2 + AHEAD - 1>{});
+        }
+        if constexpr (st.fresh) {
+          constexpr int nxt = deconv_next_fresh(S2, NG);
+          if constexpr (nxt < 2 * NSTEP) {
+            if (nxt < NSTEP || pz) aload(std::integral_constant<int, nxt>{});
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int slot = deconv_aslot(S2, NG);
+        constexpr int ring = S2 % AHEAD;
+        const f32x4 aa = abuf[slot];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const f32x4 bb = bq[ring][n];
+          acc[c][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.x, bb.x, acc[c][n], 0, 0, 0);
+          acc[c][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.y, bb.y, acc[c][n], 0, 0, 0);
+          acc[c][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.z, bb.z, acc[c][n], 0, 0, 0);
+          acc[c][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.w, bb.w, acc[c][n], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      static_for<0, AHEAD - 1>(bload);                  // steps 0..AHEAD-2 are < NSTEP
+      aload(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, NSTEP>(body);
+      if (pz) static_for<NSTEP, 2 * NSTEP>(body);
+    }
+    if (ck == nch - 1) {
+      int id = t >> 1;
+      const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
+      const int ty0 = (id % p.nty) * TY; id /= p.nty;
+      const int tz = id % p.Di; const int tb = id / p.Di;
+      const int zo = 2 * tz + pz;
+      const int ym = ty0 + wave;
+      constexpr int COUT = 32 * NT;
+      if (zo < p.Do && ym < p.Hi) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int co = n * 32 + r;
+          const float sc = p.scale ? p.scale[co] : 1.f;
+          const float sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int yo = 2 * ym + (c >> 1);
+            if (yo >= p.Ho) continue;                       // wave-uniform
+            const int xo0 = 2 * tx0 + (c & 1);              // output x of tile row 0
+            // input columns beyond Wi produce nothing: limit = min(Wo, 2*Wi)
+            const int xlimit = min(p.Wo, 2 * p.Wi);
+            float* yrow = p.y + ((((long)tb * p.Do + zo) * p.Ho + yo) * p.Wo + xo0) * COUT + co;
+            const float* rrow = p.res
+                ? p.res + ((((long)tb * p.Dr + zo) * p.Hr + yo) * p.Wr + xo0) * COUT + co : nullptr;
+            store_tile<COUT, 2>(acc[c][n], sc, sh, p.relu, yrow, rrow, h, xo0, xlimit);
+          }
         }
       }
     }
+    ck = nck; t = nt_;
+    if (t >= end) break;
   }
 }
 
@@ -337,8 +499,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
 // the scalar cache (wave-uniform addresses).
 // Weights packed as [tap][Cin].
 // ----------------------------------------------------------------------------
+// `w` is a kernel argument of its own (not a ConvParams field) so that it can be
+// __restrict__: the wave-uniform weight reads then compile to s_load (scalar cache)
+// instead of 108 per-lane vector loads per chunk.
 template <int CK>
-__global__ __launch_bounds__(NTHREADS) void conv3d_cout1_kernel(ConvParams p) {
+__global__ __launch_bounds__(NTHREADS) void conv3d_cout1_kernel(ConvParams p,
+                                                                const float* __restrict__ w) {
   constexpr int TY = 8;
   constexpr int IY = TY + 2, IX = 34, XP = 34, IZ = 3;
   constexpr int NQ = CK / 4;
@@ -370,14 +536,16 @@ __global__ __launch_bounds__(NTHREADS) void conv3d_cout1_kernel(ConvParams p) {
         if (e < NE) tile[(zz * IY + yy) * ROW + q * XP + xx] = val;
       }
       __syncthreads();
-      const float* wc = p.w + ck * CK;
+      // constant address space => wave-uniform reads become s_load_dwordx4
+      typedef const float __attribute__((address_space(4))) cfloat;
+      cfloat* wc = (cfloat*)(w) + ck * CK;
 #pragma unroll
       for (int tap = 0; tap < 27; ++tap) {
         const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const f32x4 a = tile[(dz * IY + ty + dy) * ROW + q * XP + r + dx];
-          const float* w4 = wc + (long)tap * p.Cin + q * 4;
+          cfloat* w4 = wc + tap * p.Cin + q * 4;
           acc = fmaf(a.x, w4[0], acc); acc = fmaf(a.y, w4[1], acc);
           acc = fmaf(a.z, w4[2], acc); acc = fmaf(a.w, w4[3], acc);
         }
@@ -489,15 +657,15 @@ int run_conv(ConvParams p, hipStream_t s) {
   return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK>, p, lds, s, 512);
 }
 
-template <int NT, int TM, int CK>
+template <int NT, int CK>
 int run_deconv(ConvParams p, hipStream_t s) {
-  constexpr int TY = 4 * TM;
+  constexpr int TY = 4;
   p.ntx = dsm_cdiv(p.Wi, 32); p.nty = dsm_cdiv(p.Hi, TY);
-  const long nt = (long)p.B * p.Di * p.nty * p.ntx * 8;
+  const long nt = (long)p.B * p.Di * p.nty * p.ntx * 2;       // x2: z-parity
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
   const size_t lds = (size_t)2 * (TY + 1) * (CK / 4) * 34 * 16;
-  return launch_tiles(deconv3d_mfma_kernel<NT, TM, CK>, p, lds, s, 512);
+  return launch_tiles(deconv3d_mfma_kernel<NT, CK>, p, lds, s, 512);
 }
 
 }  // namespace
@@ -558,8 +726,8 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   // Tile height: 8 rows (TM = 2) when that still gives every CU two workgroups of work,
   // else 4 rows.  Stride 2 stages 8 channels per chunk so that two workgroups fit a CU.
   if (a->transposed) {
-    const bool big = (long)a->B * a->Di * dsm_cdiv(a->Hi, 8) * dsm_cdiv(a->Wi, 32) * 8 >= 1024;
-    *pl = Plan{1, 2, NT, (big && NT <= 2) ? 2 : 1, 16};
+    DSM_REQUIRE(NT <= 2, DSM_ERR_UNSUPPORTED);   // 4 classes x NT accumulators must fit 256 VGPRs
+    *pl = Plan{1, 2, NT, 1, 16};
     return DSM_OK;
   }
   const bool big = (long)a->B * a->Do * dsm_cdiv(a->Ho, 8) * dsm_cdiv(a->Wo, 32) >= 1024;
@@ -580,7 +748,7 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
   if (rc != DSM_OK) { buf[0] = 0; return rc; }
   switch (pl.kind) {
     case 0: snprintf(buf, len, "conv3d_mfma_kernel<S=%d,NT=%d,TM=%d,CK=%d>", pl.S, pl.NT, pl.TM, pl.CK); break;
-    case 1: snprintf(buf, len, "deconv3d_mfma_kernel<NT=%d,TM=%d,CK=%d>", pl.NT, pl.TM, pl.CK); break;
+    case 1: snprintf(buf, len, "deconv3d_mfma_kernel<NT=%d,CK=%d>", pl.NT, pl.CK); break;
     case 2: snprintf(buf, len, "conv3d_cout1_kernel<CK=%d>", pl.CK); break;
     default: snprintf(buf, len, "deconv3d_cout1_kernel"); break;
   }
@@ -609,15 +777,17 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
     p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, 8);
     p.ntiles = p.B * p.Do * p.nty * p.ntx;
     const size_t lds = (size_t)3 * 10 * 4 * 34 * 16;
-    return launch_tiles(conv3d_cout1_kernel<16>, p, lds, s, 2048);
+    if (hipFuncSetAttribute((const void*)conv3d_cout1_kernel<16>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return DSM_ERR_LAUNCH;
+    const int blocks = p.ntiles < 2048 ? p.ntiles : 2048;
+    hipLaunchKernelGGL(conv3d_cout1_kernel<16>, dim3(blocks), dim3(NTHREADS), lds, s, p, p.w);
+    return dsm_launch_status();
   }
 #define DSM_CASE(KIND, S_, NT_, TM_, CK_, CALL) \
   if (pl.kind == KIND && pl.S == S_ && pl.NT == NT_ && pl.TM == TM_ && pl.CK == CK_) return CALL
-  DSM_CASE(1, 2, 1, 2, 16, (run_deconv<1, 2, 16>(p, s)));
-  DSM_CASE(1, 2, 1, 1, 16, (run_deconv<1, 1, 16>(p, s)));
-  DSM_CASE(1, 2, 2, 2, 16, (run_deconv<2, 2, 16>(p, s)));
-  DSM_CASE(1, 2, 2, 1, 16, (run_deconv<2, 1, 16>(p, s)));
-  DSM_CASE(1, 2, 4, 1, 16, (run_deconv<4, 1, 16>(p, s)));
+  DSM_CASE(1, 2, 1, 1, 16, (run_deconv<1, 16>(p, s)));
+  DSM_CASE(1, 2, 2, 1, 16, (run_deconv<2, 16>(p, s)));
   DSM_CASE(0, 1, 1, 2, 16, (run_conv<1, 1, 2, 16>(p, s)));
   DSM_CASE(0, 1, 1, 1, 16, (run_conv<1, 1, 1, 16>(p, s)));
   DSM_CASE(0, 1, 2, 2, 8, (run_conv<1, 2, 2, 8>(p, s)));

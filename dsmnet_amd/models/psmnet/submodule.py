@@ -100,6 +100,13 @@ class feature_extraction(nn.Module):
         raw = self.layer2(x)
         skip = self.layer4(self.layer3(raw))
         size = skip.shape[2:]
-        pyramid = [F.interpolate(getattr(self, "branch%d" % i)(skip), size=size,
-                                 mode="bilinear", align_corners=False) for i in (4, 3, 2, 1)]
+        # SPP pooling as a cascade: AvgPool(8), then 2x2 averages give AvgPool(16/32/64)
+        # exactly (equal windows that tile, floor semantics preserved) -- the direct 64x64
+        # pooling kernel costs 2.5 ms per forward at 384x1280 (profiles/r01_a_summary.md).
+        pooled, pyramid = skip, []
+        for i in (4, 3, 2, 1):
+            pooled = F.avg_pool2d(pooled, 8 if i == 4 else 2)
+            branch = getattr(self, "branch%d" % i)
+            y = branch[2](branch[1](pooled))          # convbn + ReLU ([0] is the AvgPool2d)
+            pyramid.append(F.interpolate(y, size=size, mode="bilinear", align_corners=False))
         return self.lastconv(torch.cat([raw, skip] + pyramid, dim=1))
