@@ -499,12 +499,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
 // the scalar cache (wave-uniform addresses).
 // Weights packed as [tap][Cin].
 // ----------------------------------------------------------------------------
-// `w` is a kernel argument of its own (not a ConvParams field) so that it can be
-// __restrict__: the wave-uniform weight reads then compile to s_load (scalar cache)
-// instead of 108 per-lane vector loads per chunk.
+// `w` is a kernel argument of its own (not a ConvParams field) and is read through the
+// constant address space, so the wave-uniform weight reads compile to s_load_dwordx4.
+// Same persistent pipeline as the MFMA kernels: the next (tile, chunk) is prefetched into
+// registers while the current chunk is reduced; CK = 8 keeps the LDS image at 32 KB so that
+// four workgroups share a CU and hide each other's barriers.
 template <int CK>
-__global__ __launch_bounds__(NTHREADS) void conv3d_cout1_kernel(ConvParams p,
-                                                                const float* __restrict__ w) {
+__global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_kernel(ConvParams p,
+                                                                   const float* __restrict__ w) {
   constexpr int TY = 8;
   constexpr int IY = TY + 2, IX = 34, XP = 34, IZ = 3;
   constexpr int NQ = CK / 4;
@@ -512,53 +514,89 @@ __global__ __launch_bounds__(NTHREADS) void conv3d_cout1_kernel(ConvParams p,
   constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
   constexpr int ROW = NQ * XP;
   extern __shared__ __attribute__((aligned(16))) f32x4 tile[];
+  typedef const float __attribute__((address_space(4))) cfloat;
   const int tid = threadIdx.x;
   const int r = tid & 31, ty = tid >> 5;
   const int nch = p.Cin / CK;
-  for (int item = blockIdx.x; item < p.ntiles; item += gridDim.x) {
-    int id = item;
-    const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
-    const int ty0 = (id % p.nty) * TY; id /= p.nty;
-    const int tz = id % p.Do; const int tb = id / p.Do;
-    float acc = 0.f;
-    for (int ck = 0; ck < nch; ++ck) {
-      __syncthreads();
+  int t = blockIdx.x;
+  const int step = gridDim.x, end = p.ntiles;
+  if (t >= end) return;
+
+  f32x4 pf[NPF];
+  auto prefetch = [&](int id, int ck) {
+    const int xb = (id % p.ntx) * 32 - 1; id /= p.ntx;
+    const int yb = (id % p.nty) * TY - 1; id /= p.nty;
+    const int zb = (id % p.Do) - 1; const int b = id / p.Do;
 #pragma unroll
-      for (int k = 0; k < NPF; ++k) {
-        const int e = tid + k * NTHREADS;
-        const int q = e % NQ, v = e / NQ;
-        const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
-        const int zi = tz - 1 + zz, yi = ty0 - 1 + yy, xi = tx0 - 1 + xx;
-        f32x4 val = {0.f, 0.f, 0.f, 0.f};
-        if (e < NE && zi >= 0 && zi < p.Di && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi)
-          val = *reinterpret_cast<const f32x4*>(
-              p.x + ((((long)tb * p.Di + zi) * p.Hi + yi) * p.Wi + xi) * p.Cin + ck * CK + q * 4);
-        if (e < NE) tile[(zz * IY + yy) * ROW + q * XP + xx] = val;
-      }
-      __syncthreads();
-      // constant address space => wave-uniform reads become s_load_dwordx4
-      typedef const float __attribute__((address_space(4))) cfloat;
-      cfloat* wc = (cfloat*)(w) + ck * CK;
+    for (int k = 0; k < NPF; ++k) {
+      const int e = tid + k * NTHREADS;
+      const int q = e % NQ, v = e / NQ;
+      const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
+      const int zi = zb + zz, yi = yb + yy, xi = xb + xx;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (e < NE && zi >= 0 && zi < p.Di && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi)
+        val = *reinterpret_cast<const f32x4*>(
+            p.x + ((((long)b * p.Di + zi) * p.Hi + yi) * p.Wi + xi) * p.Cin + ck * CK + q * 4);
+      pf[k] = val;
+    }
+  };
+  float acc = 0.f;
+  int ck = 0;
+  prefetch(t, 0);
+  while (true) {
+    __syncthreads();
 #pragma unroll
-      for (int tap = 0; tap < 27; ++tap) {
-        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+    for (int k = 0; k < NPF; ++k) {
+      const int e = tid + k * NTHREADS;
+      const int q = e % NQ, v = e / NQ;
+      const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
+      if (e < NE) tile[(zz * IY + yy) * ROW + q * XP + xx] = pf[k];
+    }
+    __syncthreads();
+    int nt_ = t, nck = ck + 1;
+    if (nck == nch) { nck = 0; nt_ = t + step; }
+    if (nt_ < end) prefetch(nt_, nck);
+    if (ck == 0) acc = 0.f;
+    // Weights and activations both count on lgkmcnt, and scalar loads return out of order,
+    // so mixing s_load with ds_read forces lgkmcnt(0) at every use.  Two pinned phases per
+    // z-tap instead: 9 x s_load_dwordx8 (72 weights into SGPRs), then the LDS reads + FMAs.
+    cfloat* wc = (cfloat*)(w) + ck * CK;
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz) {
+      float wv[9][CK];
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int c = 0; c < CK; ++c) wv[t9][c] = wc[(dz * 9 + t9) * p.Cin + c];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const int dy = t9 / 3, dx = t9 % 3;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const f32x4 a = tile[(dz * IY + ty + dy) * ROW + q * XP + r + dx];
-          cfloat* w4 = wc + tap * p.Cin + q * 4;
-          acc = fmaf(a.x, w4[0], acc); acc = fmaf(a.y, w4[1], acc);
-          acc = fmaf(a.z, w4[2], acc); acc = fmaf(a.w, w4[3], acc);
+          acc = fmaf(a.x, wv[t9][4 * q + 0], acc); acc = fmaf(a.y, wv[t9][4 * q + 1], acc);
+          acc = fmaf(a.z, wv[t9][4 * q + 2], acc); acc = fmaf(a.w, wv[t9][4 * q + 3], acc);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    const int yo = ty0 + ty, xo = tx0 + r;
-    if (yo < p.Ho && xo < p.Wo) {
-      float v = acc * (p.scale ? p.scale[0] : 1.f) + (p.shift ? p.shift[0] : 0.f);
-      if (p.relu == 2) v = fmaxf(v, 0.f);
-      if (p.res) v += p.res[(((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo];
-      if (p.relu == 1) v = fmaxf(v, 0.f);
-      p.y[(((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo] = v;
+    if (ck == nch - 1) {
+      int id = t;
+      const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
+      const int ty0 = (id % p.nty) * TY; id /= p.nty;
+      const int tz = id % p.Do; const int tb = id / p.Do;
+      const int yo = ty0 + ty, xo = tx0 + r;
+      if (yo < p.Ho && xo < p.Wo) {
+        float v = acc * (p.scale ? p.scale[0] : 1.f) + (p.shift ? p.shift[0] : 0.f);
+        if (p.relu == 2) v = fmaxf(v, 0.f);
+        if (p.res) v += p.res[(((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo];
+        if (p.relu == 1) v = fmaxf(v, 0.f);
+        p.y[(((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo] = v;
+      }
     }
+    ck = nck; t = nt_;
+    if (t >= end) break;
   }
 }
 
@@ -701,7 +739,7 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   DSM_REQUIRE(a->stride == 1 || a->stride == 2, DSM_ERR_UNSUPPORTED);
   DSM_REQUIRE(!a->transposed || a->stride == 2, DSM_ERR_UNSUPPORTED);
   DSM_REQUIRE(a->relu >= 0 && a->relu <= 2, DSM_ERR_ARG);
-  DSM_REQUIRE(a->Cin % 16 == 0, DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(a->Cin % 16 == 0, DSM_ERR_UNSUPPORTED);   // chunk sizes 8 and 16 both divide it
   DSM_REQUIRE(dsm_aligned16(a->x) && dsm_aligned16(a->w_packed) && dsm_aligned16(a->y),
               DSM_ERR_ALIGN);
   // natural output size; the caller may ask for a smaller corner (crop-add), never more
@@ -717,7 +755,7 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
       *pl = Plan{3, 2, 0, 0, 0};
     } else {
       DSM_REQUIRE(a->stride == 1, DSM_ERR_UNSUPPORTED);
-      *pl = Plan{2, 1, 0, 0, 16};
+      *pl = Plan{2, 1, 0, 0, 8};
     }
     return DSM_OK;
   }
@@ -776,12 +814,9 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   if (pl.kind == 2) {
     p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, 8);
     p.ntiles = p.B * p.Do * p.nty * p.ntx;
-    const size_t lds = (size_t)3 * 10 * 4 * 34 * 16;
-    if (hipFuncSetAttribute((const void*)conv3d_cout1_kernel<16>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return DSM_ERR_LAUNCH;
-    const int blocks = p.ntiles < 2048 ? p.ntiles : 2048;
-    hipLaunchKernelGGL(conv3d_cout1_kernel<16>, dim3(blocks), dim3(NTHREADS), lds, s, p, p.w);
+    const size_t lds = (size_t)3 * 10 * 2 * 34 * 16;              // CK = 8: 32.6 KB
+    const int blocks = p.ntiles < 1024 ? p.ntiles : 1024;          // 4 workgroups per CU
+    hipLaunchKernelGGL(conv3d_cout1_kernel<8>, dim3(blocks), dim3(NTHREADS), lds, s, p, p.w);
     return dsm_launch_status();
   }
 #define DSM_CASE(KIND, S_, NT_, TM_, CK_, CALL) \

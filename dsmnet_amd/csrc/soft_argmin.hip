@@ -128,6 +128,80 @@ __global__ __launch_bounds__(256) void soft_argmin_fwd_kernel(SaParams p) {
   }
 }
 
+// Fast path for the PSMNet head: D == 4*Dc, align_corners = 0.  torch's source index
+// (d + 0.5)/4 - 0.5 makes the four fine bins of coarse interval k
+//   v(4k+0) = .375 P[k-1] + .625 P[k]     v(4k+1) = .125 P[k-1] + .875 P[k]
+//   v(4k+2) = .875 P[k]   + .125 P[k+1]   v(4k+3) = .625 P[k]   + .375 P[k+1]
+// with P[-1] := P[0], P[Dc] := P[Dc-1] (the clamps), P[k] the pixel's bilinear sample of
+// coarse plane k.  No per-bin index arithmetic; an exact two-pass softmax (pass 1: max of
+// the fine values, pass 2: one v_exp per bin) replaces the branchy online update.
+template <int DSPLIT>
+__global__ __launch_bounds__(256) void soft_argmin_up4_kernel(SaParams p) {
+  constexpr int PXW = DSM_WAVE / DSPLIT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg = lane / PXW;
+  const int x = (blockIdx.x * 4 + wave) * PXW + (lane % PXW);
+  const int y = blockIdx.y, b = blockIdx.z;
+  const bool live = x < p.W;
+  const int kper = (p.Dc + DSPLIT - 1) / DSPLIT;
+  const int k_lo = seg * kper, k_hi = min(p.Dc, k_lo + kper);
+  Sm acc = {-INFINITY, 0.f, 0.f};
+  if (live && k_lo < k_hi) {
+    const Lerp ly = lerp_at(y, p.sh, p.Hc, p.H, 0);
+    const Lerp lx = lerp_at(x, p.sw, p.Wc, p.W, 0);
+    Stencil st;
+    st.o00 = ly.i0 * p.Wc + lx.i0; st.o01 = ly.i0 * p.Wc + lx.i1;
+    st.o10 = ly.i1 * p.Wc + lx.i0; st.o11 = ly.i1 * p.Wc + lx.i1;
+    st.wy0 = ly.w0; st.wy1 = ly.w1; st.wx0 = lx.w0; st.wx1 = lx.w1;
+    const long ps = (long)p.Hc * p.Wc;
+    const float* base = p.cost + (long)b * p.Dc * ps;
+    const float sg = p.sign;
+    // pass 1: exact maximum of the fine values of this segment
+    float Pm = sg * plane_at(base, ps, max(k_lo - 1, 0), st);
+    float Pc = sg * plane_at(base, ps, k_lo, st);
+    float m = -INFINITY;
+    for (int k = k_lo; k < k_hi; ++k) {
+      const float Pn = sg * plane_at(base, ps, min(k + 1, p.Dc - 1), st);
+      const float v0 = 0.375f * Pm + 0.625f * Pc, v1 = 0.125f * Pm + 0.875f * Pc;
+      const float v2 = 0.875f * Pc + 0.125f * Pn, v3 = 0.625f * Pc + 0.375f * Pn;
+      m = fmaxf(m, fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
+      Pm = Pc; Pc = Pn;
+    }
+    // pass 2: sums
+    Pm = sg * plane_at(base, ps, max(k_lo - 1, 0), st);
+    Pc = sg * plane_at(base, ps, k_lo, st);
+    float l = 0.f, sum = 0.f;
+    for (int k = k_lo; k < k_hi; ++k) {
+      const float Pn = sg * plane_at(base, ps, min(k + 1, p.Dc - 1), st);
+      const float d0 = (float)(4 * k);
+      const float e0 = __expf(0.375f * Pm + 0.625f * Pc - m);
+      const float e1 = __expf(0.125f * Pm + 0.875f * Pc - m);
+      const float e2 = __expf(0.875f * Pc + 0.125f * Pn - m);
+      const float e3 = __expf(0.625f * Pc + 0.375f * Pn - m);
+      l += (e0 + e1) + (e2 + e3);
+      sum = fmaf(d0, e0, sum); sum = fmaf(d0 + 1.f, e1, sum);
+      sum = fmaf(d0 + 2.f, e2, sum); sum = fmaf(d0 + 3.f, e3, sum);
+      Pm = Pc; Pc = Pn;
+    }
+    acc.m = m; acc.l = l; acc.s = sum;
+  }
+#pragma unroll
+  for (int off = PXW; off < DSM_WAVE; off <<= 1) {
+    Sm o;
+    o.m = __shfl_xor(acc.m, off); o.l = __shfl_xor(acc.l, off); o.s = __shfl_xor(acc.s, off);
+    acc = sm_merge(acc, o);
+  }
+  if (live && seg == 0) {
+    const long o = ((long)b * p.H + y) * p.W + x;
+    p.disp[o] = acc.s / acc.l;
+    if (p.stats) {
+      const long hw = (long)p.H * p.W;
+      p.stats[(long)b * 2 * hw + (long)y * p.W + x] = acc.m;
+      p.stats[(long)b * 2 * hw + hw + (long)y * p.W + x] = acc.l;
+    }
+  }
+}
+
 // Backward: dcost_fine[d] = sign * p_d * (d - E) * g, then (PSMNet form) the adjoint
 // of the trilinear stencil.  One thread per full-resolution pixel walks d; the
 // contributions to a coarse plane are summed in registers and leave as 4 float
@@ -246,7 +320,13 @@ extern "C" int dsm_soft_argmin_fwd(const void* cost, void* disp, void* stats, in
   hipStream_t s = (hipStream_t)stream;
   dsm_clear_stale_error();
 #define SA_LAUNCH(UP, DS) hipLaunchKernelGGL((soft_argmin_fwd_kernel<UP, DS>), grid, block, 0, s, p)
-  if (up) { if (ds == 4) SA_LAUNCH(true, 4); else if (ds == 2) SA_LAUNCH(true, 2); else SA_LAUNCH(true, 1); }
+  static int generic_only = -1;                       // DSM_SOFTARGMIN_GENERIC=1 forces the generic kernel (A/B)
+  if (generic_only < 0) { const char* e = getenv("DSM_SOFTARGMIN_GENERIC"); generic_only = e ? atoi(e) : 0; }
+  if (up && !generic_only && D == 4 * Dc && !align_corners && Dc >= ds) {
+    if (ds == 4) hipLaunchKernelGGL(soft_argmin_up4_kernel<4>, grid, block, 0, s, p);
+    else if (ds == 2) hipLaunchKernelGGL(soft_argmin_up4_kernel<2>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(soft_argmin_up4_kernel<1>, grid, block, 0, s, p);
+  } else if (up) { if (ds == 4) SA_LAUNCH(true, 4); else if (ds == 2) SA_LAUNCH(true, 2); else SA_LAUNCH(true, 1); }
   else    { if (ds == 4) SA_LAUNCH(false, 4); else if (ds == 2) SA_LAUNCH(false, 2); else SA_LAUNCH(false, 1); }
 #undef SA_LAUNCH
   return dsm_launch_status();
