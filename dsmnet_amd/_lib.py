@@ -25,7 +25,8 @@ class Conv3dArgs(ctypes.Structure):
                 ("Di", c_int), ("Hi", c_int), ("Wi", c_int),
                 ("Do", c_int), ("Ho", c_int), ("Wo", c_int),
                 ("Dr", c_int), ("Hr", c_int), ("Wr", c_int),
-                ("stride", c_int), ("transposed", c_int), ("relu", c_int)]
+                ("stride", c_int), ("transposed", c_int), ("relu", c_int),
+                ("kd", c_int), ("k", c_int), ("dil", c_int)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in dsmnet_hip.h
@@ -40,6 +41,7 @@ SIGNATURES = {
     "dsm_soft_argmin_bwd": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
     "dsm_conv3d_packed_weight_bytes": (c_size_t, [c_int] * 3),
     "dsm_conv3d_pack_weights": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
+    "dsm_conv_pack_weights": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "dsm_conv3d_fwd": (c_int, [ctypes.POINTER(Conv3dArgs), c_void_p]),
     "dsm_conv3d_plan": (c_int, [ctypes.POINTER(Conv3dArgs), ctypes.c_char_p, c_int]),
     "dsm_volume_relayout": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
@@ -80,7 +82,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.dsm_abi_version() != 1:
+    if lib.dsm_abi_version() != 2:
         raise DsmnetHipError("libdsmnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -1,0 +1,108 @@
+"""2-D tower blocks: ``Sequential(Conv2d, BatchNorm2d)`` with the
+reference's child indices (``convbn`` -- models/psmnet/submodule.py:10-13), run in eval mode
+on the GPU as ONE launch of the MFMA convolution kernel with folded BN, fused ReLU and skip
+add, on NHWC (``torch.channels_last``) maps.
+
+Training mode, CPU tensors, and layer shapes the kernel does not cover (e.g. the SPP branches'
+1x1 convolution with padding 1) run the stock torch modules: the towers are outside the
+cost-volume hot path, so stock layers are legitimate there (autograd included).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import costvolume as cv
+from .blocks3d import _versions
+
+
+def fused_ok(conv, x):
+    """Can ``conv`` (an nn.Conv2d) run on the MFMA kernel for input ``x``?"""
+    if not (isinstance(conv, nn.Conv2d) and x.is_cuda and x.dtype == torch.float32):
+        return False
+    k, s, d, p = conv.kernel_size, conv.stride, conv.dilation, conv.padding
+    if k[0] != k[1] or s[0] != s[1] or d[0] != d[1] or p[0] != p[1] or conv.groups != 1:
+        return False
+    if k[0] not in (1, 3) or s[0] not in (1, 2) or d[0] not in (1, 2):
+        return False
+    if p[0] != d[0] * (k[0] - 1) // 2 or conv.padding_mode != "zeros":
+        return False
+    if conv.out_channels not in (32, 64, 128):
+        return False
+    cin = x.shape[1]
+    if cin % 16 != 0 or cin < conv.in_channels:
+        return False
+    # variants compiled in csrc/conv3d.hip (DSM_CASE2D)
+    key = (s[0], conv.out_channels // 32, k[0], d[0])
+    return key in {(1, 1, 3, 1), (1, 2, 3, 1), (1, 4, 3, 1), (1, 4, 3, 2), (2, 1, 3, 1),
+                   (2, 2, 3, 1), (1, 1, 1, 1), (1, 4, 1, 1), (2, 2, 1, 1)}
+
+
+class _Folded2d(object):
+    def __init__(self):
+        self.key = None
+        self.packed = self.scale = self.shift = None
+
+    def get(self, conv, bn, cin_padded):
+        srcs = [conv.weight, conv.bias]
+        if bn is not None:
+            srcs += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = _versions(*srcs) + (cin_padded,)
+        if key != self.key:
+            with torch.no_grad():
+                self.packed = cv.pack_conv2d_weight(conv.weight, cin_padded)
+                if bn is not None:
+                    inv = torch.rsqrt(bn.running_var + bn.eps)
+                    scale = bn.weight * inv if bn.weight is not None else inv
+                    shift = -bn.running_mean * scale
+                    if bn.bias is not None:
+                        shift = shift + bn.bias
+                    if conv.bias is not None:
+                        shift = shift + conv.bias * scale
+                    self.scale, self.shift = scale.contiguous(), shift.contiguous()
+                elif conv.bias is not None:
+                    self.scale = torch.ones_like(conv.bias)
+                    self.shift = conv.bias.detach().clone()
+                else:
+                    self.scale = self.shift = None
+            self.key = key
+        return self.packed, self.scale, self.shift
+
+
+def run_conv2d(folded, conv, bn, x, residual=None, relu=False):
+    """conv (+BN) (+skip) (+ReLU): fused when possible, stock torch otherwise."""
+    training = bn is not None and bn.training
+    if not training and not torch.is_grad_enabled() and fused_ok(conv, x):
+        packed, scale, shift = folded.get(conv, bn, x.shape[1])
+        return cv.conv2d_block(x, packed, conv.out_channels, scale, shift, residual,
+                               stride=conv.stride[0], relu=1 if relu else 0,
+                               k=conv.kernel_size[0], dilation=conv.dilation[0])
+    if x.shape[1] != conv.in_channels:            # zero-padded staging channels
+        x = x[:, : conv.in_channels]
+    y = conv(x)
+    if bn is not None:
+        y = bn(y)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+class ConvBN2d(nn.Sequential):
+    """``convbn``'s Sequential(Conv2d, BatchNorm2d); ``forward(x)`` equals it."""
+
+    def __init__(self, conv, bn):
+        super(ConvBN2d, self).__init__(conv, bn)
+        self._folded = _Folded2d()
+
+    def forward(self, x, residual=None, relu=False):
+        return run_conv2d(self._folded, self[0], self[1], x, residual, relu)
+
+
+def stage_image_nhwc16(img):
+    """(B,3,H,W) image -> (B,16,H,W) channels_last with zero channels 3..15, the 16-channel
+    granularity the MFMA kernel stages (the first convolution's weights are zero-padded to match)."""
+    B, C, H, W = img.shape
+    out = torch.empty((B, 16, H, W), device=img.device, dtype=img.dtype,
+                      memory_format=torch.channels_last)
+    out[:, :C] = img
+    out[:, C:] = 0
+    return out

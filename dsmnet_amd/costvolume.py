@@ -345,3 +345,59 @@ def conv3d_plan_name(args):
     buf = ctypes.create_string_buffer(96)
     _lib.check(_lib.load().dsm_conv3d_plan(ctypes.byref(args), buf, 96), "dsm_conv3d_plan")
     return buf.value.decode()
+
+
+# ----------------------------------------------------------------------------
+# 2-D convolution block (feature towers): same MFMA kernel, kd = 1
+# ----------------------------------------------------------------------------
+_CL2D = torch.channels_last
+
+
+def pack_conv2d_weight(weight, cin_padded=None):
+    """torch Conv2d weight (Cout, Cin, k, k), k in {1, 3} -> MFMA fragment order.  ``cin_padded``
+    (a multiple of 16 >= Cin) zero-fills the extra input channels."""
+    _require_device("pack_conv2d_weight", weight)
+    cout, cin, kh, kw = weight.shape
+    if kh != kw or kh not in (1, 3):
+        raise ValueError("conv2d_block supports 1x1 and 3x3 kernels, got %dx%d" % (kh, kw))
+    cin_p = cin if cin_padded is None else int(cin_padded)
+    w = weight.detach().contiguous()
+    packed = torch.empty(cin_p * cout * kh * kw, device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        rc = _lib.load().dsm_conv_pack_weights(_p(w), _p(packed), cin, cin_p, cout, 1, kh, _stream())
+    _lib.check(rc, "dsm_conv_pack_weights")
+    return packed
+
+
+def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, stride=1,
+                 relu=0, k=3, dilation=1):
+    """y = relu?(conv2d(x) * scale + shift (+ residual)) on NHWC maps, "same" padding.
+    ``x``: (B, Cin, H, W) in torch.channels_last memory, Cin a multiple of 16.  Inference only."""
+    _require_device("conv2d_block", x, packed_weight, scale, shift, residual)
+    if not x.is_contiguous(memory_format=_CL2D):
+        x = x.contiguous(memory_format=_CL2D)
+    B, cin, Hi, Wi = x.shape
+    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    a = _lib.Conv3dArgs()
+    if residual is not None:
+        if tuple(residual.shape) != (B, cout, Ho, Wo):
+            raise ValueError("conv2d_block: residual shape %s != %s"
+                             % (tuple(residual.shape), (B, cout, Ho, Wo)))
+        if not residual.is_contiguous(memory_format=_CL2D):
+            residual = residual.contiguous(memory_format=_CL2D)
+        a.Dr, a.Hr, a.Wr = 1, Ho, Wo
+    y = torch.empty((B, cout, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=_CL2D)
+    a.x, a.w_packed, a.y = x.data_ptr(), packed_weight.data_ptr(), y.data_ptr()
+    a.scale = None if scale is None else scale.data_ptr()
+    a.shift = None if shift is None else shift.data_ptr()
+    a.residual = None if residual is None else residual.data_ptr()
+    a.B, a.Cin, a.Cout = B, cin, cout
+    a.Di, a.Hi, a.Wi = 1, Hi, Wi
+    a.Do, a.Ho, a.Wo = 1, Ho, Wo
+    a.stride, a.transposed, a.relu = int(stride), 0, int(relu)
+    a.kd, a.k, a.dil = 1, int(k), int(dilation)
+    work = 2.0 * k * k * cin * cout * B * Ho * Wo
+    with torch.cuda.device(x.device), _timed(lambda: conv3d_plan_name(a), work):
+        rc = _lib.load().dsm_conv3d_fwd(ctypes.byref(a), _stream())
+    _lib.check(rc, "dsm_conv3d_fwd")
+    return y

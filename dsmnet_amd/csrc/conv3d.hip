@@ -51,11 +51,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 constexpr int NTHREADS = 256;
 
-template <int S> struct Geo {
-  // input-tile extents for an output tile of TY rows x 32 columns, one z
-  static constexpr int IZ = 3;
-  static __host__ __device__ constexpr int IY(int TY) { return (TY - 1) * S + 3; }
-  static constexpr int IX = 31 * S + 3;                 // 34 or 65
+// Input-tile geometry for an output tile of TY rows x 32 columns, one z.
+// KZ x KXY x KXY taps (KZ = 1: a 2-D convolution on (B,1,H,W,C) volumes), dilation DIL in
+// (y, x), padding = "same" ((K-1)/2 * dilation), stride S.
+template <int S, int KZ = 3, int KXY = 3, int DIL = 1> struct Geo {
+  static constexpr int IZ = KZ;
+  static constexpr int EXT = (KXY - 1) * DIL;           // halo span in y and x
+  static constexpr int PADZ = (KZ - 1) / 2, PADXY = EXT / 2;
+  static constexpr int NTAP = KZ * KXY * KXY;
+  static __host__ __device__ constexpr int IY(int TY) { return (TY - 1) * S + EXT + 1; }
+  static constexpr int IX = 31 * S + EXT + 1;           // 34 or 65 for the 3x3x3 trunk
   static constexpr int XE = (IX + 1) / 2;               // even columns when S == 2
   static constexpr int XP = (S == 1) ? IX : 2 * XE;     // LDS row pitch in 16-B elements
   static __host__ __device__ constexpr int xmap(int x) {
@@ -129,11 +134,14 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, float sc, float sh
 }
 
 // ----------------------------------------------------------------------------
-// Conv3d(k=3, padding=1, stride=S), Cout = 32*NT, Cin = multiple of CK.
+// Conv(KZ x KXY x KXY, "same" padding, dilation DIL, stride S), Cout = 32*NT, Cin = multiple
+// of CK.  KZ = 3, KXY = 3: the 3-D trunk.  KZ = 1: the 2-D feature towers (3x3, 3x3
+// dilated, 1x1) on (B,1,H,W,C) views of NHWC maps -- SURVEY.md section 8f-1.
 // ----------------------------------------------------------------------------
-template <int S, int NT, int TM, int CK>
+template <int S, int NT, int TM, int CK, int KZ = 3, int KXY = 3, int DIL = 1>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) {
-  using G = Geo<S>;
+  using G = Geo<S, KZ, KXY, DIL>;
+  constexpr int NTAP = G::NTAP;
   constexpr int TY = 4 * TM;
   constexpr int IY = G::IY(TY), IX = G::IX, XP = G::XP, IZ = G::IZ;
   constexpr int NQ = CK / 4;                    // 16-B slots per voxel per chunk
@@ -161,9 +169,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
     tz = id % p.Do; tb = id / p.Do;
   };
   auto prefetch = [&](int id, int ck) {
-    int xb = (id % p.ntx) * 32 * S - 1; id /= p.ntx;
-    int yb = (id % p.nty) * TY * S - 1; id /= p.nty;
-    int zb = (id % p.Do) * S - 1; const int b = id / p.Do;
+    int xb = (id % p.ntx) * 32 * S - G::PADXY; id /= p.ntx;
+    int yb = (id % p.nty) * TY * S - G::PADXY; id /= p.nty;
+    int zb = (id % p.Do) * S - G::PADZ; const int b = id / p.Do;
 #pragma unroll
     for (int k = 0; k < NPF; ++k) {
       const int e = tid + k * NTHREADS;
@@ -214,21 +222,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
     // AHEAD-1 items before use (>= 1.5k cycles of MFMA cover the L2 round trip), the next
     // item's A fragments one item before use; each MFMA cluster runs on operands that were
     // requested at least one full cluster earlier.
-    constexpr int NITEM = 27 * NG;
-    constexpr int AHEAD = (TM * NT >= 4) ? 3 : ((TM * NT >= 2) ? 4 : 6);
+    constexpr int NITEM = NTAP * NG;
+    constexpr int AHEAD0 = (TM * NT >= 4) ? 3 : ((TM * NT >= 2) ? 4 : 6);
+    constexpr int AHEAD = AHEAD0 < NITEM ? AHEAD0 : NITEM;
     f32x4 bq[AHEAD][NT];
     f32x4 abuf[2][TM];
-    const f32x4* wbase = wp + (long)ck * NG * 27 * NT * 64 + lane;   // [g][tap][nt][lane]
+    const f32x4* wbase = wp + (long)ck * NG * NTAP * NT * 64 + lane;   // [g][tap][nt][lane]
     auto bload = [&](auto ic) {
       constexpr int item = decltype(ic)::value;
       constexpr int tap = item / NG, gi = item % NG;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bq[item % AHEAD][n] = wbase[((gi * 27 + tap) * NT + n) * 64];
+      for (int n = 0; n < NT; ++n) bq[item % AHEAD][n] = wbase[((gi * NTAP + tap) * NT + n) * 64];
     };
     auto aload = [&](auto ic) {
       constexpr int item = decltype(ic)::value;
       constexpr int tap = item / NG, gi = item % NG;
-      constexpr int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      constexpr int dz = tap / (KXY * KXY), dy = ((tap / KXY) % KXY) * DIL, dx = (tap % KXY) * DIL;
       constexpr int xoff = (S == 1) ? dx : ((dx & 1) * G::XE + (dx >> 1));
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
@@ -641,9 +650,11 @@ __global__ __launch_bounds__(NTHREADS) void deconv3d_cout1_kernel(ConvParams p) 
 // ----------------------------------------------------------------------------
 // Weight packing (once per layer): torch layout -> MFMA B-fragment order.
 // ----------------------------------------------------------------------------
+// ntaps = 27 (3x3x3), 9 (3x3) or 1 (1x1).  cin_src <= Cin: source input channels; channels
+// beyond it are packed as zeros (PSMNet's first convolution has 3, staged as 16).
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin,
-                                    int Cout, int transposed) {
-  const long n = (long)Cin * Cout * 27;
+                                    int Cout, int transposed, int ntaps, int cin_src) {
+  const long n = (long)Cin * Cout * ntaps;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
   int cin, cout, tap;
@@ -655,19 +666,19 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     const int j = i & 3; i >>= 2;
     const int lane = i & 63; i >>= 6;
     const int n_ = i % NT; i /= NT;
-    tap = i % 27; const int g = i / 27;
+    tap = i % ntaps; const int g = i / ntaps;
     cin = 8 * g + 4 * (lane >> 5) + j;
     cout = 32 * n_ + (lane & 31);
   }
-  const long src = transposed ? (((long)cin * Cout + cout) * 27 + tap)
-                              : (((long)cout * Cin + cin) * 27 + tap);
-  out[idx] = w[src];
+  const long src = transposed ? (((long)cin * Cout + cout) * ntaps + tap)
+                              : (((long)cout * cin_src + cin) * ntaps + tap);
+  out[idx] = (cin < cin_src) ? w[src] : 0.f;
 }
 
 template <typename K>
 int launch_tiles(K kernel, const ConvParams& p, size_t lds, hipStream_t s, int max_blocks) {
   if (lds > 64 * 1024) {
-    static thread_local const void* configured[16];
+    static thread_local const void* configured[48];
     static thread_local int nconf = 0;
     bool seen = false;
     for (int i = 0; i < nconf; ++i) seen |= (configured[i] == (const void*)kernel);
@@ -675,7 +686,7 @@ int launch_tiles(K kernel, const ConvParams& p, size_t lds, hipStream_t s, int m
       if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds) != hipSuccess)
         return DSM_ERR_LAUNCH;
-      if (nconf < 16) configured[nconf++] = (const void*)kernel;
+      if (nconf < 48) configured[nconf++] = (const void*)kernel;
     }
   }
   int blocks = p.ntiles < max_blocks ? p.ntiles : max_blocks;
@@ -684,15 +695,16 @@ int launch_tiles(K kernel, const ConvParams& p, size_t lds, hipStream_t s, int m
   return dsm_launch_status();
 }
 
-template <int S, int NT, int TM, int CK>
+template <int S, int NT, int TM, int CK, int KZ = 3, int KXY = 3, int DIL = 1>
 int run_conv(ConvParams p, hipStream_t s) {
+  using G = Geo<S, KZ, KXY, DIL>;
   constexpr int TY = 4 * TM;
   p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, TY);
   const long nt = (long)p.B * p.Do * p.nty * p.ntx;
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
-  const size_t lds = (size_t)3 * Geo<S>::IY(TY) * (CK / 4) * Geo<S>::XP * 16;
-  return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK>, p, lds, s, 512);
+  const size_t lds = (size_t)G::IZ * G::IY(TY) * (CK / 4) * G::XP * 16;
+  return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK, KZ, KXY, DIL>, p, lds, s, 512);
 }
 
 template <int NT, int CK>
@@ -723,13 +735,28 @@ extern "C" int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed, int 
   dsm_clear_stale_error();
   hipLaunchKernelGGL(pack_weights_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const float*)w_torch, (float*)w_packed, Cin, Cout,
-                     transposed);
+                     transposed, 27, Cin);
+  return dsm_launch_status();
+}
+
+extern "C" int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, int Cin,
+                                     int Cout, int kd, int k, dsm_stream_t stream) {
+  DSM_REQUIRE(w_torch && w_packed && w_torch != w_packed, DSM_ERR_ARG);
+  DSM_REQUIRE(Cin_src > 0 && Cin >= Cin_src && Cout > 0, DSM_ERR_ARG);
+  DSM_REQUIRE((kd == 1 || kd == 3) && (k == 1 || k == 3), DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(Cin % 16 == 0 && Cout % 32 == 0, DSM_ERR_UNSUPPORTED);
+  const int ntaps = kd * k * k;
+  const long n = (long)Cin * Cout * ntaps;
+  dsm_clear_stale_error();
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const float*)w_torch, (float*)w_packed, Cin, Cout, 0,
+                     ntaps, Cin_src);
   return dsm_launch_status();
 }
 
 namespace {
 // One place decides the kernel variant; dsm_conv3d_fwd launches it, dsm_conv3d_plan names it.
-struct Plan { int kind; int S, NT, TM, CK; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1
+struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1
 
 int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   DSM_REQUIRE(a && a->x && a->w_packed && a->y, DSM_ERR_ARG);
@@ -742,6 +769,11 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   DSM_REQUIRE(a->Cin % 16 == 0, DSM_ERR_UNSUPPORTED);   // chunk sizes 8 and 16 both divide it
   DSM_REQUIRE(dsm_aligned16(a->x) && dsm_aligned16(a->w_packed) && dsm_aligned16(a->y),
               DSM_ERR_ALIGN);
+  const int kd = a->kd ? a->kd : 3, k = a->k ? a->k : 3, dil = a->dil ? a->dil : 1;
+  DSM_REQUIRE((kd == 1 || kd == 3) && (k == 1 || k == 3) && (dil == 1 || dil == 2),
+              DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(kd == 3 ? (k == 3 && dil == 1) : (!a->transposed && a->Di == 1 && a->Cout != 1),
+              DSM_ERR_UNSUPPORTED);
   // natural output size; the caller may ask for a smaller corner (crop-add), never more
   const int nD = a->transposed ? 2 * a->Di : (a->Di - 1) / a->stride + 1;
   const int nH = a->transposed ? 2 * a->Hi : (a->Hi - 1) / a->stride + 1;
@@ -752,10 +784,10 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   if (a->Cout == 1) {
     if (a->transposed) {
       DSM_REQUIRE(a->Ho <= 65535 && (long)a->B * a->Do <= 65535, DSM_ERR_UNSUPPORTED);
-      *pl = Plan{3, 2, 0, 0, 0};
+      *pl = Plan{3, 2, 0, 0, 0, 3, 3, 1};
     } else {
       DSM_REQUIRE(a->stride == 1, DSM_ERR_UNSUPPORTED);
-      *pl = Plan{2, 1, 0, 0, 8};
+      *pl = Plan{2, 1, 0, 0, 8, 3, 3, 1};
     }
     return DSM_OK;
   }
@@ -765,15 +797,20 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   // else 4 rows.  Stride 2 stages 8 channels per chunk so that two workgroups fit a CU.
   if (a->transposed) {
     DSM_REQUIRE(NT <= 2, DSM_ERR_UNSUPPORTED);   // 4 classes x NT accumulators must fit 256 VGPRs
-    *pl = Plan{1, 2, NT, 1, 16};
+    *pl = Plan{1, 2, NT, 1, 16, 3, 3, 1};
     return DSM_OK;
   }
   const bool big = (long)a->B * a->Do * dsm_cdiv(a->Ho, 8) * dsm_cdiv(a->Wo, 32) >= 1024;
+  if (kd == 1) {                                   // 2-D towers: one staged slice, 16-channel chunks
+    const int TM = (big && NT == 1 && a->stride == 1 && k == 3 && dil == 1) ? 2 : 1;
+    *pl = Plan{0, a->stride, NT, TM, 16, 1, k, dil};
+    return DSM_OK;
+  }
   if (a->stride == 1) {
     const int TM = (big && NT <= 2) ? 2 : 1;
-    *pl = Plan{0, 1, NT, TM, (NT == 2 && TM == 2) ? 8 : 16};   // <1,2,2,16> would spill
+    *pl = Plan{0, 1, NT, TM, (NT == 2 && TM == 2) ? 8 : 16, 3, 3, 1};   // <1,2,2,16> would spill
   } else {
-    *pl = Plan{0, 2, NT, 1, 8};
+    *pl = Plan{0, 2, NT, 1, 8, 3, 3, 1};
   }
   return DSM_OK;
 }
@@ -785,7 +822,10 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
   int rc = make_plan(a, &pl);
   if (rc != DSM_OK) { buf[0] = 0; return rc; }
   switch (pl.kind) {
-    case 0: snprintf(buf, len, "conv3d_mfma_kernel<S=%d,NT=%d,TM=%d,CK=%d>", pl.S, pl.NT, pl.TM, pl.CK); break;
+    case 0:
+      if (pl.KZ == 3) snprintf(buf, len, "conv3d_mfma_kernel<S=%d,NT=%d,TM=%d,CK=%d>", pl.S, pl.NT, pl.TM, pl.CK);
+      else snprintf(buf, len, "conv2d_mfma_kernel<S=%d,NT=%d,TM=%d,K=%d,DIL=%d>", pl.S, pl.NT, pl.TM, pl.K, pl.DIL);
+      break;
     case 1: snprintf(buf, len, "deconv3d_mfma_kernel<NT=%d,CK=%d>", pl.NT, pl.CK); break;
     case 2: snprintf(buf, len, "conv3d_cout1_kernel<CK=%d>", pl.CK); break;
     default: snprintf(buf, len, "deconv3d_cout1_kernel"); break;
@@ -819,6 +859,15 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
     hipLaunchKernelGGL(conv3d_cout1_kernel<8>, dim3(blocks), dim3(NTHREADS), lds, s, p, p.w);
     return dsm_launch_status();
   }
+#define DSM_CASE2D(S_, NT_, TM_, K_, DIL_) \
+  if (pl.kind == 0 && pl.KZ == 1 && pl.S == S_ && pl.NT == NT_ && pl.TM == TM_ && pl.K == K_ && \
+      pl.DIL == DIL_) return run_conv<S_, NT_, TM_, 16, 1, K_, DIL_>(p, s)
+  DSM_CASE2D(1, 1, 1, 3, 1); DSM_CASE2D(1, 1, 2, 3, 1); DSM_CASE2D(1, 2, 1, 3, 1);
+  DSM_CASE2D(1, 4, 1, 3, 1); DSM_CASE2D(1, 4, 1, 3, 2);
+  DSM_CASE2D(2, 1, 1, 3, 1); DSM_CASE2D(2, 2, 1, 3, 1);
+  DSM_CASE2D(1, 1, 1, 1, 1); DSM_CASE2D(1, 4, 1, 1, 1); DSM_CASE2D(2, 2, 1, 1, 1);
+#undef DSM_CASE2D
+  if (pl.KZ == 1) return DSM_ERR_UNSUPPORTED;
 #define DSM_CASE(KIND, S_, NT_, TM_, CK_, CALL) \
   if (pl.kind == KIND && pl.S == S_ && pl.NT == NT_ && pl.TM == TM_ && pl.CK == CK_) return CALL
   DSM_CASE(1, 2, 1, 1, 16, (run_deconv<1, 16>(p, s)));

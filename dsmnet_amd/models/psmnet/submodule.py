@@ -12,13 +12,14 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import costvolume as cv
+from ...blocks2d import ConvBN2d, _Folded2d, run_conv2d, stage_image_nhwc16
 from ...blocks3d import ConvBN3d
 
 
 def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
     # the reference pads by `dilation` whatever `pad` says (submodule.py:10-13); kept.
     del pad
-    return nn.Sequential(
+    return ConvBN2d(
         nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
                   padding=dilation, dilation=dilation, bias=False),
         nn.BatchNorm2d(out_planes))
@@ -42,8 +43,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        y = self.conv2(self.conv1(x))
-        return y + (x if self.downsample is None else self.downsample(x))
+        y = self.conv1[0](x, relu=True)                    # convbn + the Sequential's ReLU
+        skip = x if self.downsample is None else self.downsample(x)
+        return self.conv2(y, residual=skip)                # convbn + skip add, no ReLU after
 
 
 class disparityregression(nn.Module):
@@ -86,7 +88,7 @@ class feature_extraction(nn.Module):
     def _make_layer(self, block, planes, blocks, stride, pad, dilation):
         downsample = None
         if stride != 1 or self.inplanes != planes * block.expansion:
-            downsample = nn.Sequential(
+            downsample = ConvBN2d(
                 nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1,
                           stride=stride, bias=False),
                 nn.BatchNorm2d(planes * block.expansion))
@@ -96,7 +98,11 @@ class feature_extraction(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.layer1(self.firstconv(x))
+        if x.is_cuda and not self.training and not torch.is_grad_enabled():
+            x = stage_image_nhwc16(x)                      # NHWC, 3 -> 16 staged channels
+        for i in (0, 2, 4):
+            x = self.firstconv[i](x, relu=True)
+        x = self.layer1(x)
         raw = self.layer2(x)
         skip = self.layer4(self.layer3(raw))
         size = skip.shape[2:]
@@ -107,6 +113,10 @@ class feature_extraction(nn.Module):
         for i in (4, 3, 2, 1):
             pooled = F.avg_pool2d(pooled, 8 if i == 4 else 2)
             branch = getattr(self, "branch%d" % i)
-            y = branch[2](branch[1](pooled))          # convbn + ReLU ([0] is the AvgPool2d)
+            y = branch[1](pooled, relu=True)          # convbn + ReLU ([0] is the AvgPool2d)
             pyramid.append(F.interpolate(y, size=size, mode="bilinear", align_corners=False))
-        return self.lastconv(torch.cat([raw, skip] + pyramid, dim=1))
+        x = torch.cat([raw, skip] + pyramid, dim=1)
+        x = self.lastconv[0](x, relu=True)
+        if not hasattr(self, "_last_fold"):
+            self._last_fold = _Folded2d()
+        return run_conv2d(self._last_fold, self.lastconv[2], None, x)

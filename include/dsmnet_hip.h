@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DSM_ABI_VERSION 1
+#define DSM_ABI_VERSION 2
 
 #define DSM_OK               0
 #define DSM_ERR_ARG         -1   /* null pointer, non-positive size, bad enum      */
@@ -137,6 +137,13 @@ typedef struct dsm_conv3d_args {
   int stride;
   int transposed;
   int relu;               /* 0 none, 1 after the skip add, 2 before it */
+  /* kernel geometry; 0 = default.  kd = 1 selects the 2-D form (Di = Do = 1, NHWC maps as
+   * (B,1,H,W,C) volumes) used for the 2-D feature towers:
+   * k in {1,3}, dil in {1,2}, padding = dil*(k-1)/2 ("same"), as in convbn()
+   * (models/psmnet/submodule.py:10-13) for k = 3 and the towers' 1x1 convolutions. */
+  int kd;                 /* depth taps: 3 (default) or 1            */
+  int k;                  /* taps in y and x: 3 (default) or 1       */
+  int dil;                /* dilation in y and x: 1 (default) or 2   */
 } dsm_conv3d_args;
 
 /* bytes of the packed (MFMA-fragment-ordered) weight buffer */
@@ -145,6 +152,12 @@ size_t dsm_conv3d_packed_weight_bytes(int Cin, int Cout, int transposed);
 /* w_torch: torch layout, (Cout,Cin,3,3,3) or, transposed, (Cin,Cout,3,3,3). */
 int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed,
                             int Cin, int Cout, int transposed, dsm_stream_t stream);
+
+/* General packer: kd x k x k taps, torch layout (Cout, Cin_src, [kd,] k, k); input channels
+ * Cin_src..Cin-1 are packed as zeros (PSMNet's first convolution: 3 staged as 16).
+ * Bytes needed: Cin*Cout*kd*k*k*4. */
+int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, int Cin, int Cout,
+                          int kd, int k, dsm_stream_t stream);
 
 int dsm_conv3d_fwd(const dsm_conv3d_args* args, dsm_stream_t stream);
 
