@@ -25,7 +25,16 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, stamps=False):
+    """stamps=True: diagnostic build with in-kernel s_memtime phase stamps
+    (libdsmnet_hip_stamps.so; never loaded by the package)."""
+    if stamps:
+        lib = os.path.join(HERE, "libdsmnet_hip_stamps.so")
+        srcs = [os.path.join(HERE, s) for s in SOURCES]
+        cmd = [HIPCC] + FLAGS + ["-DDSM_STAMPS", "-shared", "-o", lib] + srcs
+        print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return lib
     hdrs = [os.path.join(HERE, "common.hpp"),
             os.path.join(HERE, "..", "..", "include", "dsmnet_hip.h")]
     srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
@@ -54,4 +63,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, stamps="--stamps" in sys.argv))

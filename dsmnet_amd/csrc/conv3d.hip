@@ -29,12 +29,42 @@
 //  * weights are pre-packed once per layer into MFMA B-fragment order
 //    [cin/8][tap][cout/32][lane][4] and streamed from L2 with 16 B per lane,
 //    three fragments ahead of their use;
-//  * epilogue: y = acc*scale[co] + shift[co] (+ skip) (ReLU), 128 B per voxel.
+//  * MFMA operands are (weights, activations), so a lane owns one voxel and 4-channel
+//    register quads: epilogue y = acc*scale + shift (+ skip) (ReLU) moves 16 B per lane.
 //
 // K order inside an 8-channel group: MFMA step j multiplies channels
 // {8g + j (lanes 0-31), 8g + 4 + j (lanes 32-63)}; A and B fragments agree on it.
 #include "common.hpp"
 #include <type_traits>
+
+#ifdef DSM_STAMPS
+// Diagnostic build only (python dsmnet_amd/csrc/build.py --stamps): per-phase cycle totals of
+// wave 0 of every workgroup, read back with dsm_debug_read_stamps.  Never in the shipped build.
+__device__ unsigned long long dsm_stamp_buf[8 * 1024];
+#define DSM_STAMP(slot)                                                                  \
+  do {                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    unsigned long long _t;                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) dsm_stamp_buf[blockIdx.x * 8 + (slot)] += _t - _tprev; \
+    _tprev = _t;                                                                         \
+  } while (0)
+#define DSM_STAMP_INIT()                                                                 \
+  unsigned long long _tprev;                                                             \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_tprev)::"memory")
+extern "C" int dsm_debug_read_stamps(unsigned long long* host, int zero) {
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(dsm_stamp_buf), sizeof(unsigned long long) * 8 * 1024) != hipSuccess) return -3;
+  if (zero) {
+    static unsigned long long z[8 * 1024];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(dsm_stamp_buf), z, sizeof(z)) != hipSuccess) return -3;
+  }
+  return 0;
+}
+#else
+#define DSM_STAMP(slot) do {} while (0)
+#define DSM_STAMP_INIT() do {} while (0)
+#endif
 
 namespace {
 
@@ -75,6 +105,8 @@ struct ConvParams {
   int Di, Hi, Wi, Do, Ho, Wo, Dr, Hr, Wr;
   int relu;
   int ntx, nty, ntiles;       // tile grid: x tiles, y tiles, total = B*Do*nty*ntx (x8 classes for deconv)
+  unsigned xbytes, wbytes;    // extents of x and w for the buffer descriptors (< 4 GiB)
+  int stagger;                // units of s_sleep(127) (~8k cycles) for the odd wave slot; 0 = off
 };
 
 // XCD-aware persistent tile order: workgroups are dealt round-robin over the 8
@@ -91,45 +123,141 @@ __device__ __forceinline__ int first_tile(int ntiles, int& step, int& end) {
   return lo + slot;
 }
 
-// Epilogue of one 32x32 accumulator tile: rows = 32 consecutive x of one output row (stride
-// XS voxels in memory: 1 for convolutions, 2 for a transposed-conv parity class), columns =
-// 32 output channels on the lanes.  y = acc*sc + sh (ReLU?) (+ skip) (ReLU?).
-// Interior tiles (wave-uniform test) take a branch-free path with all 16 skip loads in flight
-// and compile-time address offsets; edge tiles fall back to per-element guards.
-template <int COUT, int XS>
-__device__ __forceinline__ void store_tile(const f32x16& acc, float sc, float sh, int relu,
-                                           float* __restrict__ yrow, const float* __restrict__ rrow,
-                                           int h, int xbase, int xlimit) {
-  // yrow / rrow point at voxel (row start, x = xbase-th output column), channel co of this lane
-  constexpr int VS = COUT * XS;                       // floats between consecutive tile rows
-  float* yp = yrow + (long)(4 * h) * VS;
-  const float* rp = rrow ? rrow + (long)(4 * h) * VS : nullptr;
-  if (xbase + 31 * XS < xlimit) {                     // whole tile inside the row
-    float r[16];
-    if (rp) {
+// Epilogue of one 32x32 accumulator tile.  The MFMAs are issued with the WEIGHT fragment as
+// the A operand and the activation fragment as B, so the tile comes out transposed: lane
+// (r = lane & 31, h = lane >> 5) owns output voxel r of the row and register k holds channel
+// (k & 3) + 8 (k >> 2) + 4 h -- four consecutive channels per register quad, i.e. 16
+// contiguous bytes of the NDHWC voxel.  Each lane therefore issues 4 dwordx4 stores (and 4
+// dwordx4 skip loads) per tile instead of 16 dword ones: the store tail is issue-bound, not
+// bandwidth-bound (measured: ~20k cycles per tile with dword stores).
+//   y = acc*scale + shift (ReLU?) (+ skip) (ReLU?)
+// `yv` / `rv` point at this lane's voxel, channel 32*n + 4*h; XS = voxel stride between
+// consecutive lanes (1, or 2 for a transposed-conv parity class).
+template <int COUT>
+__device__ __forceinline__ void store_tile(const f32x16& acc, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, int relu,
+                                           float* __restrict__ yv, const float* __restrict__ rv,
+                                           int cbase) {
+  f32x4 r4[4];
+  if (rv) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) r[i] = rp[((i & 3) + 8 * (i >> 2)) * VS];
-    }
+    for (int g = 0; g < 4; ++g) r4[g] = *reinterpret_cast<const f32x4*>(rv + 8 * g);
+  }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float v = acc[i] * sc + sh;
-      if (relu == 2) v = fmaxf(v, 0.f);
-      if (rp) v += r[i];
-      if (relu == 1) v = fmaxf(v, 0.f);
-      yp[((i & 3) + 8 * (i >> 2)) * VS] = v;
-    }
-  } else {
+  for (int g = 0; g < 4; ++g) {
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const f32x4*>(scale + cbase + 8 * g);
+    if (shift) sh = *reinterpret_cast<const f32x4*>(shift + cbase + 8 * g);
+    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    v = v * sc + sh;
+    if (relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (rv) v += r4[g];
+    if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<f32x4*>(yv + 8 * g) = v;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// Staging of one channel chunk of a halo tile: global -> registers -> LDS.
+//
+// On gfx950 the fp32 MFMA shares the SIMD's vector ALU ("runs at the vector rate"): every
+// VALU instruction of either resident wave is time taken from the matrix pipe (stamps: two
+// workgroups per CU spend 2 x 27.6k cycles in MFMAs + 2 x 6.6k in VALU per pair of chunks,
+// and staging code that runs 3k cycles alone takes 14k beside a multiplying partner).  So
+// the staging path is built to issue (almost) no VALU:
+//  * the LDS image is stored in element order e = ((z*IY + y)*IX + x)*NQ + q and thread
+//    `tid` owns elements e = tid + 256*k: a commit is NPF ds_write_b128 with immediate
+//    offsets (the A-fragment reads then have a 4-way bank conflict, irrelevant beside
+//    64-cycle MFMAs);
+//  * each thread's global offsets are computed once per launch; a chunk whose halo box lies
+//    inside the volume (wave-uniform test) is staged by loads of the form
+//    scalar base + 32-bit register offset, zero VALU; boxes that stick out of the volume
+//    (edge tiles) take a guarded path that decodes coordinates on the fly;
+//  * the loads are issued one per item inside the multiply loop.
+// ----------------------------------------------------------------------------
+// 16-byte load through a buffer descriptor: address = descriptor base + voffset (VGPR, fixed per
+// lane) + soffset (SGPR).  No address VALU at all, which is the point here (T8 in the guide).
+__device__ __forceinline__ f32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset,
+                                               unsigned soffset) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voffset, (int)soffset, 0);
+  static_assert(sizeof(v) == 16, "raw_buffer_load_b128 must return 16 bytes");
+  return __builtin_bit_cast(f32x4, v);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <int NPF, int NE, int NQ, int IX, int IY>
+__device__ __forceinline__ void stage_offsets(unsigned (&off)[NPF], int tid, int Hi, int Wi,
+                                              int Cin) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (xbase + row * XS < xlimit) {
-        float v = acc[i] * sc + sh;
-        if (relu == 2) v = fmaxf(v, 0.f);
-        if (rp) v += rp[((i & 3) + 8 * (i >> 2)) * VS];
-        if (relu == 1) v = fmaxf(v, 0.f);
-        yp[((i & 3) + 8 * (i >> 2)) * VS] = v;
-      }
-    }
+  for (int k = 0; k < NPF; ++k) {
+    const int e = min(tid + k * NTHREADS, NE - 1);
+    const int q = e % NQ, v = e / NQ;
+    const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
+    off[k] = 4u * (unsigned)(((zz * Hi + yy) * Wi + xx) * Cin + 4 * q);      // bytes
+  }
+}
+
+struct StageBox {
+  const float* base;      // address of the box origin (may lie outside the volume at the edges)
+  unsigned sbase;         // its byte offset from the tensor start (valid when `interior`)
+  int zb, yb, xb;         // box origin in input coordinates
+  int Di, Hi, Wi;
+  bool interior;          // the whole box lies inside the volume (wave-uniform)
+  bool active;            // there is a next item at all
+};
+
+__device__ __forceinline__ StageBox stage_box(const float* __restrict__ x, int b, int zb, int yb,
+                                              int xb, int Di, int Hi, int Wi, int Cin, int c0,
+                                              int IZ, int IY, int IX, bool active) {
+  StageBox s;
+  const long origin = ((((long)b * Di + zb) * Hi + yb) * Wi + xb) * Cin + c0;
+  s.base = x + origin;
+  s.sbase = (unsigned)(origin * 4);
+  s.zb = zb; s.yb = yb; s.xb = xb; s.Di = Di; s.Hi = Hi; s.Wi = Wi;
+  s.interior = active && zb >= 0 && zb + IZ <= Di && yb >= 0 && yb + IY <= Hi && xb >= 0 &&
+               xb + IX <= Wi;
+  s.active = active;
+  return s;
+}
+
+// Element k of the box (k a compile-time constant).
+template <int K, int NE, int NQ, int IX, int IY>
+__device__ __forceinline__ f32x4 stage_load(const StageBox& s, __amdgpu_buffer_rsrc_t xrsrc,
+                                            unsigned off, int tid) {
+  constexpr bool tail = (K + 1) * NTHREADS > NE;       // the last slice may be partial
+  if (s.interior && !tail) return buffer_load16(xrsrc, off, s.sbase);
+  f32x4 val = {0.f, 0.f, 0.f, 0.f};
+  const int e = tid + K * NTHREADS;
+  bool ok = s.active && e < NE;
+  if (!s.interior) {
+    const int v = e / NQ;
+    const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
+    ok = ok && (unsigned)(s.zb + zz) < (unsigned)s.Di && (unsigned)(s.yb + yy) < (unsigned)s.Hi &&
+         (unsigned)(s.xb + xx) < (unsigned)s.Wi;
+  }
+  if (ok) val = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s.base) + off);
+  return val;
+}
+
+template <int NPF, int NE, int NQ, int IX, int IY>
+__device__ __forceinline__ void stage_prefetch(f32x4 (&pf)[NPF], const unsigned (&off)[NPF],
+                                               const StageBox& s, __amdgpu_buffer_rsrc_t xrsrc,
+                                               int tid) {
+  static_for<0, NPF>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    pf[k] = stage_load<k, NE, NQ, IX, IY>(s, xrsrc, off[k], tid);
+  });
+}
+
+template <int NPF, int NE>
+__device__ __forceinline__ void stage_commit(f32x4* __restrict__ tile, const f32x4 (&pf)[NPF],
+                                             int tid) {
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) {
+    if ((k + 1) * NTHREADS <= NE) tile[tid + k * NTHREADS] = pf[k];
+    else if (tid + k * NTHREADS < NE) tile[tid + k * NTHREADS] = pf[k];
   }
 }
 
@@ -143,13 +271,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
   using G = Geo<S, KZ, KXY, DIL>;
   constexpr int NTAP = G::NTAP;
   constexpr int TY = 4 * TM;
-  constexpr int IY = G::IY(TY), IX = G::IX, XP = G::XP, IZ = G::IZ;
+  constexpr int IY = G::IY(TY), IX = G::IX, IZ = G::IZ;
   constexpr int NQ = CK / 4;                    // 16-B slots per voxel per chunk
   constexpr int NG = CK / 8;                    // 8-channel MFMA groups per chunk
   constexpr int NE = IZ * IY * IX * NQ;         // staged 16-B elements per chunk
   constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
-  constexpr int ROW = NQ * XP;                  // elements per (z, y) row
-  extern __shared__ __attribute__((aligned(16))) f32x4 tile[];   // [IZ][IY][NQ][XP]
+  extern __shared__ __attribute__((aligned(16))) f32x4 tile[];   // [IZ][IY][IX][NQ], element order
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -168,46 +295,58 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
     ty0 = (id % p.nty) * TY; id /= p.nty;
     tz = id % p.Do; tb = id / p.Do;
   };
-  auto prefetch = [&](int id, int ck) {
-    int xb = (id % p.ntx) * 32 * S - G::PADXY; id /= p.ntx;
-    int yb = (id % p.nty) * TY * S - G::PADXY; id /= p.nty;
-    int zb = (id % p.Do) * S - G::PADZ; const int b = id / p.Do;
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-      const int e = tid + k * NTHREADS;
-      const int q = e % NQ, v = e / NQ;
-      const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
-      const int zi = zb + zz, yi = yb + yy, xi = xb + xx;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (e < NE && zi >= 0 && zi < p.Di && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi)
-        val = *reinterpret_cast<const f32x4*>(
-            p.x + ((((long)b * p.Di + zi) * p.Hi + yi) * p.Wi + xi) * p.Cin + ck * CK + q * 4);
-      pf[k] = val;
-    }
+  unsigned goff[NPF];
+  stage_offsets<NPF, NE, NQ, IX, IY>(goff, tid, p.Hi, p.Wi, p.Cin);
+  const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(p.x, p.xbytes);
+  const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.wbytes);
+  auto box_of = [&](int id, int ck, bool active) {
+    const int xb = (id % p.ntx) * 32 * S - G::PADXY; id /= p.ntx;
+    const int yb = (id % p.nty) * TY * S - G::PADXY; id /= p.nty;
+    const int zb = (id % p.Do) * S - G::PADZ; const int b = id / p.Do;
+    return stage_box(p.x, b, zb, yb, xb, p.Di, p.Hi, p.Wi, p.Cin, ck * CK, IZ, IY, IX, active);
   };
-  auto commit = [&]() {
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-      const int e = tid + k * NTHREADS;
-      const int q = e % NQ, v = e / NQ;
-      const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
-      if (e < NE) tile[(zz * IY + yy) * ROW + q * XP + G::xmap(xx)] = pf[k];
-    }
-  };
+  auto commit = [&]() { stage_commit<NPF, NE>(tile, pf, tid); };
 
   f32x16 acc[TM][NT];
-  const int lane_el = h * XP + r;               // this lane's slot within a (z,y) row
+  const int lane_el = r * S * NQ + h;           // this lane's element within an image row
   int ck = 0;
-  prefetch(t, 0);
+  {
+    const StageBox first = box_of(t, 0, true);
+    stage_prefetch<NPF, NE, NQ, IX, IY>(pf, goff, first, xrsrc, tid);
+  }
+  // Stagger.  The two workgroups resident on a CU run the same program on equal tiles and
+  // fall into lockstep: both stage / store at once (matrix pipe idle), then both multiply
+  // (sharing the pipe) -- period = N + 2M instead of 2M (stamps: multiply phase exactly 2x
+  // the single-wave time).  Delaying the wave in the odd hardware slot of its SIMD by about
+  // half a chunk, once, puts one workgroup's non-MFMA phases under the other's MFMAs.
+  // Placement-dependent for speed only (HW_REG_HW_ID wave_id), never for correctness.
+  if (p.stagger) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);   // HW_ID[3:0]
+    if (hw & 1u) {
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
+  DSM_STAMP_INIT();
+  // Issue priority: a wave in its staging / epilogue phases competes for issue slots with the
+  // partner workgroup's MFMA stream and, being the younger or equal-priority wave, gets the
+  // leftovers (measured: 5k cycles of staging alone -> 15-19k beside a multiplying partner).
+  // An MFMA needs one issue slot per 64 cycles, so the multiply phase runs at priority 0 and
+  // everything else at 3.
+  __builtin_amdgcn_s_setprio(3);
   while (true) {
     __syncthreads();                            // every wave is done with the old chunk
+    DSM_STAMP(0);                               // [0] wait at barrier 1
     commit();
+    DSM_STAMP(1);                               // [1] vmcnt wait for the prefetch + LDS commit
     __syncthreads();
-    // next (tile, chunk) item -> registers; lands while this chunk is multiplied
+    DSM_STAMP(2);                               // [2] barrier 2
+    // next (tile, chunk): its NPF staged loads are issued one per item INSIDE the multiply
+    // loop, in the shadow of this wave's own MFMAs -- as a separate phase they crawl whenever
+    // the partner workgroup is streaming fp32 MFMAs (14k cycles instead of 3k; stamps).
     int nt_ = t, nck = ck + 1;
     if (nck == nch) { nck = 0; nt_ = t + step; }
-    if (nt_ < end) prefetch(nt_, nck);
-
+    const StageBox nbox = box_of(nt_ < end ? nt_ : t, nck, nt_ < end);
+    DSM_STAMP(3);                               // [3] next-box scalar setup
     if (ck == 0) {
 #pragma unroll
       for (int m = 0; m < TM; ++m)
@@ -216,6 +355,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
     }
+    DSM_STAMP(6);                               // [6] accumulator reset
+
     // ---- multiply: 27 taps x NG groups ------------------------------------------------
     // Software pipeline, pinned with sched_barrier(0) (left alone, hipcc sinks the loads
     // next to their first use and waits vmcnt(0) per item): B fragments are requested
@@ -227,31 +368,44 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
     constexpr int AHEAD = AHEAD0 < NITEM ? AHEAD0 : NITEM;
     f32x4 bq[AHEAD][NT];
     f32x4 abuf[2][TM];
-    const f32x4* wbase = wp + (long)ck * NG * NTAP * NT * 64 + lane;   // [g][tap][nt][lane]
+    // [g][tap][nt][lane]: wave-uniform base (SGPRs) + this lane's fixed 16-B slot, so that a
+    // B-fragment load is `global_load_dwordx4 v, v_lane, s[base]` with no address VALU
+    const unsigned wchunk = (unsigned)ck * (NG * NTAP * NT * 64 * 16);   // bytes, wave-uniform
+    const unsigned lane16 = lane * 16u;
     auto bload = [&](auto ic) {
       constexpr int item = decltype(ic)::value;
       constexpr int tap = item / NG, gi = item % NG;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bq[item % AHEAD][n] = wbase[((gi * NTAP + tap) * NT + n) * 64];
+      for (int n = 0; n < NT; ++n)
+        bq[item % AHEAD][n] =
+            buffer_load16(wrsrc, lane16, wchunk + (((gi * NTAP + tap) * NT + n) * 64) * 16);
     };
     auto aload = [&](auto ic) {
       constexpr int item = decltype(ic)::value;
       constexpr int tap = item / NG, gi = item % NG;
       constexpr int dz = tap / (KXY * KXY), dy = ((tap / KXY) % KXY) * DIL, dx = (tap % KXY) * DIL;
-      constexpr int xoff = (S == 1) ? dx : ((dx & 1) * G::XE + (dx >> 1));
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
-        const int yy = (wave * TM + m) * S + dy;
-        abuf[item & 1][m] = tile[(dz * IY + yy) * ROW + (2 * gi) * XP + xoff + lane_el];
+        const int yy = (wave * TM + m) * S + dy;       // image element ((z*IY + y)*IX + x)*NQ + q
+        abuf[item & 1][m] = tile[((dz * IY + yy) * IX + dx) * NQ + 2 * gi + lane_el];
       }
     };
     static_for<0, AHEAD - 1>(bload);
     aload(std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
+    DSM_STAMP(7);                               // [7] B/A ring prologue issue
+    __builtin_amdgcn_s_setprio(0);
     static_for<0, NITEM>([&](auto ic) {
       constexpr int item = decltype(ic)::value;
       if constexpr (item + AHEAD - 1 < NITEM) bload(std::integral_constant<int, item + AHEAD - 1>{});
       if constexpr (item + 1 < NITEM) aload(std::integral_constant<int, item + 1>{});
+      // staged loads of the next chunk, spread over the items (NPF <= NITEM for every variant
+      // except the 1x1 kernels, whose remainder is issued with the last item)
+      constexpr int PF_PER = (NPF + NITEM - 1) / NITEM;
+      static_for<0, PF_PER>([&](auto jc) {
+        constexpr int k = item * PF_PER + decltype(jc)::value;
+        if constexpr (k < NPF) pf[k] = stage_load<k, NE, NQ, IX, IY>(nbox, xrsrc, goff[k], tid);
+      });
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < TM; ++m)
@@ -259,33 +413,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
         for (int n = 0; n < NT; ++n) {
           const f32x4 aa = abuf[item & 1][m];
           const f32x4 bb = bq[item % AHEAD][n];
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.x, bb.x, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.y, bb.y, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.z, bb.z, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.w, bb.w, acc[m][n], 0, 0, 0);
+          // A operand = weights (rows: channels), B operand = activations (columns: voxels)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.x, aa.x, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.y, aa.y, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.z, aa.z, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.w, aa.w, acc[m][n], 0, 0, 0);
         }
       __builtin_amdgcn_sched_barrier(0);
     });
+    __builtin_amdgcn_s_setprio(3);
+    DSM_STAMP(4);                               // [4] multiply (item loop)
     // ---- epilogue after the last chunk of a tile --------------------------------
     if (ck == nch - 1) {
       decode(t);
       constexpr int COUT = 32 * NT;
+      const int xo = tx0 + r;                                 // this lane's output voxel
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int co = n * 32 + r;
-        const float sc = p.scale ? p.scale[co] : 1.f;
-        const float sh = p.shift ? p.shift[co] : 0.f;
+      for (int m = 0; m < TM; ++m) {
+        const int yo = ty0 + wave * TM + m;
+        if (yo >= p.Ho || xo >= p.Wo) continue;
+        const long vox = (((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo;
+        const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
 #pragma unroll
-        for (int m = 0; m < TM; ++m) {
-          const int yo = ty0 + wave * TM + m;
-          if (yo >= p.Ho) continue;                         // wave-uniform
-          float* yrow = p.y + ((((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + tx0) * COUT + co;
-          const float* rrow = p.res
-              ? p.res + ((((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + tx0) * COUT + co : nullptr;
-          store_tile<COUT, 1>(acc[m][n], sc, sh, p.relu, yrow, rrow, h, tx0, p.Wo);
+        for (int n = 0; n < NT; ++n) {
+          const int cbase = n * 32 + 4 * h;
+          store_tile<COUT>(acc[m][n], p.scale, p.shift, p.relu, p.y + vox * COUT + cbase,
+                           p.res ? p.res + rvox * COUT + cbase : nullptr, cbase);
         }
       }
     }
+    DSM_STAMP(5);                               // [5] epilogue
     ck = nck; t = nt_;
     if (t >= end) break;
   }
@@ -343,51 +500,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
   constexpr int NQ = CK / 4, NG = CK / 8;
   constexpr int NE = IZ * IY * IX * NQ;
   constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
-  constexpr int ROW = NQ * XP;
   extern __shared__ __attribute__((aligned(16))) f32x4 tile[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nch = p.Cin / CK;
   const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(p.w);
-  const int lane_el = h * XP + r;
+  const int lane_el = r * NQ + h;                        // element within an image row
 
   int step, end;
   int t = first_tile(p.ntiles, step, end);
   if (t >= end) return;
 
   f32x4 pf[NPF];
+  unsigned goff[NPF];
+  stage_offsets<NPF, NE, NQ, IX, IY>(goff, tid, p.Hi, p.Wi, p.Cin);
+  const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(p.x, p.xbytes);
+  const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.wbytes);
   auto prefetch = [&](int id, int ck) {
     id >>= 1;                                            // drop the z-parity bit
     const int xb = (id % p.ntx) * 32; id /= p.ntx;
     const int yb = (id % p.nty) * TY; id /= p.nty;
     const int zb = id % p.Di; const int b = id / p.Di;
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-      const int e = tid + k * NTHREADS;
-      const int q = e % NQ, v = e / NQ;
-      const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
-      const int zi = zb + zz, yi = yb + yy, xi = xb + xx;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (e < NE && zi < p.Di && yi < p.Hi && xi < p.Wi)
-        val = *reinterpret_cast<const f32x4*>(
-            p.x + ((((long)b * p.Di + zi) * p.Hi + yi) * p.Wi + xi) * p.Cin + ck * CK + q * 4);
-      pf[k] = val;
-    }
+    const StageBox box = stage_box(p.x, b, zb, yb, xb, p.Di, p.Hi, p.Wi, p.Cin, ck * CK, IZ, IY,
+                                   IX, true);
+    stage_prefetch<NPF, NE, NQ, IX, IY>(pf, goff, box, xrsrc, tid);
   };
-  auto commit = [&]() {
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-      const int e = tid + k * NTHREADS;
-      const int q = e % NQ, v = e / NQ;
-      const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
-      if (e < NE) tile[(zz * IY + yy) * ROW + q * XP + xx] = pf[k];
-    }
-  };
+  auto commit = [&]() { stage_commit<NPF, NE>(tile, pf, tid); };
 
   f32x16 acc[4][NT];                                     // class = py*2 + px
   int ck = 0;
   prefetch(t, 0);
+  __builtin_amdgcn_s_setprio(3);                         // see conv3d_mfma_kernel
   while (true) {
     __syncthreads();
     commit();
@@ -404,7 +548,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
           for (int i = 0; i < 16; ++i) acc[c][n][i] = 0.f;
     }
     const int pz = t & 1;
-    const f32x4* wbase = wp + (long)ck * NG * 27 * NT * 64 + lane;
+    const unsigned wchunk = (unsigned)ck * (NG * 27 * NT * 64 * 16);      // bytes, wave-uniform
+    const unsigned lane16 = lane * 16u;
     {
       // Both z taps of a z-odd item (iz = 0, 1) run as one pipelined sequence of
       // 2*NSTEP steps; a z-even item stops after NSTEP (wave-uniform branch).  Same pinned
@@ -423,14 +568,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
         const int tap = ((iz ? 0 : kz0) * 3 + ky) * 3 + kx;
         constexpr int ring = S2 % AHEAD;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bq[ring][n] = wbase[((st.gi * 27 + tap) * NT + n) * 64];
+        for (int n = 0; n < NT; ++n)
+          bq[ring][n] = buffer_load16(wrsrc, lane16, wchunk + (((st.gi * 27 + tap) * NT + n) * 64) * 16);
       };
       auto aload = [&](auto sc) {                       // slot = parity of the fresh-read count
         constexpr int S2 = decltype(sc)::value;
         constexpr int iz = S2 / NSTEP, s = S2 % NSTEP;
         constexpr DeconvStep st = deconv_step(s, NG);
         constexpr int slot = deconv_aslot(S2, NG);
-        abuf[slot] = tile[(iz * IY + wave + st.iy) * ROW + (2 * st.gi) * XP + st.ix + lane_el];
+        abuf[slot] = tile[((iz * IY + wave + st.iy) * IX + st.ix) * NQ + 2 * st.gi + lane_el];
       };
       auto body = [&](auto sc) {
         constexpr int S2 = decltype(sc)::value;
@@ -454,18 +600,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const f32x4 bb = bq[ring][n];
-          acc[c][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.x, bb.x, acc[c][n], 0, 0, 0);
-          acc[c][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.y, bb.y, acc[c][n], 0, 0, 0);
-          acc[c][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.z, bb.z, acc[c][n], 0, 0, 0);
-          acc[c][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa.w, bb.w, acc[c][n], 0, 0, 0);
+          acc[c][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.x, aa.x, acc[c][n], 0, 0, 0);
+          acc[c][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.y, aa.y, acc[c][n], 0, 0, 0);
+          acc[c][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.z, aa.z, acc[c][n], 0, 0, 0);
+          acc[c][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.w, aa.w, acc[c][n], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       };
       static_for<0, AHEAD - 1>(bload);                  // steps 0..AHEAD-2 are < NSTEP
       aload(std::integral_constant<int, 0>{});
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
       static_for<0, NSTEP>(body);
       if (pz) static_for<NSTEP, 2 * NSTEP>(body);
+      __builtin_amdgcn_s_setprio(3);
     }
     if (ck == nch - 1) {
       int id = t >> 1;
@@ -473,25 +621,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
       const int ty0 = (id % p.nty) * TY; id /= p.nty;
       const int tz = id % p.Di; const int tb = id / p.Di;
       const int zo = 2 * tz + pz;
-      const int ym = ty0 + wave;
+      const int ym = ty0 + wave, xm = tx0 + r;               // this lane's input-grid position
       constexpr int COUT = 32 * NT;
-      if (zo < p.Do && ym < p.Hi) {
+      if (zo < p.Do && ym < p.Hi && xm < p.Wi) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const int co = n * 32 + r;
-          const float sc = p.scale ? p.scale[co] : 1.f;
-          const float sh = p.shift ? p.shift[co] : 0.f;
+        for (int c = 0; c < 4; ++c) {
+          const int yo = 2 * ym + (c >> 1), xo = 2 * xm + (c & 1);
+          if (yo >= p.Ho || xo >= p.Wo) continue;
+          const long vox = (((long)tb * p.Do + zo) * p.Ho + yo) * p.Wo + xo;
+          const long rvox = (((long)tb * p.Dr + zo) * p.Hr + yo) * p.Wr + xo;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int yo = 2 * ym + (c >> 1);
-            if (yo >= p.Ho) continue;                       // wave-uniform
-            const int xo0 = 2 * tx0 + (c & 1);              // output x of tile row 0
-            // input columns beyond Wi produce nothing: limit = min(Wo, 2*Wi)
-            const int xlimit = min(p.Wo, 2 * p.Wi);
-            float* yrow = p.y + ((((long)tb * p.Do + zo) * p.Ho + yo) * p.Wo + xo0) * COUT + co;
-            const float* rrow = p.res
-                ? p.res + ((((long)tb * p.Dr + zo) * p.Hr + yo) * p.Wr + xo0) * COUT + co : nullptr;
-            store_tile<COUT, 2>(acc[c][n], sc, sh, p.relu, yrow, rrow, h, xo0, xlimit);
+          for (int n = 0; n < NT; ++n) {
+            const int cbase = n * 32 + 4 * h;
+            store_tile<COUT>(acc[c][n], p.scale, p.shift, p.relu, p.y + vox * COUT + cbase,
+                             p.res ? p.res + rvox * COUT + cbase : nullptr, cbase);
           }
         }
       }
@@ -521,7 +664,6 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_kernel(ConvParams p,
   constexpr int NQ = CK / 4;
   constexpr int NE = IZ * IY * IX * NQ;
   constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
-  constexpr int ROW = NQ * XP;
   extern __shared__ __attribute__((aligned(16))) f32x4 tile[];
   typedef const float __attribute__((address_space(4))) cfloat;
   const int tid = threadIdx.x;
@@ -532,35 +674,23 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_kernel(ConvParams p,
   if (t >= end) return;
 
   f32x4 pf[NPF];
+  unsigned goff[NPF];
+  stage_offsets<NPF, NE, NQ, IX, IY>(goff, tid, p.Hi, p.Wi, p.Cin);
+  const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(p.x, p.xbytes);
   auto prefetch = [&](int id, int ck) {
     const int xb = (id % p.ntx) * 32 - 1; id /= p.ntx;
     const int yb = (id % p.nty) * TY - 1; id /= p.nty;
     const int zb = (id % p.Do) - 1; const int b = id / p.Do;
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-      const int e = tid + k * NTHREADS;
-      const int q = e % NQ, v = e / NQ;
-      const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
-      const int zi = zb + zz, yi = yb + yy, xi = xb + xx;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (e < NE && zi >= 0 && zi < p.Di && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi)
-        val = *reinterpret_cast<const f32x4*>(
-            p.x + ((((long)b * p.Di + zi) * p.Hi + yi) * p.Wi + xi) * p.Cin + ck * CK + q * 4);
-      pf[k] = val;
-    }
+    const StageBox box = stage_box(p.x, b, zb, yb, xb, p.Di, p.Hi, p.Wi, p.Cin, ck * CK, IZ, IY,
+                                   IX, true);
+    stage_prefetch<NPF, NE, NQ, IX, IY>(pf, goff, box, xrsrc, tid);
   };
   float acc = 0.f;
   int ck = 0;
   prefetch(t, 0);
   while (true) {
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-      const int e = tid + k * NTHREADS;
-      const int q = e % NQ, v = e / NQ;
-      const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
-      if (e < NE) tile[(zz * IY + yy) * ROW + q * XP + xx] = pf[k];
-    }
+    stage_commit<NPF, NE>(tile, pf, tid);
     __syncthreads();
     int nt_ = t, nck = ck + 1;
     if (nck == nch) { nck = 0; nt_ = t + step; }
@@ -583,7 +713,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_kernel(ConvParams p,
         const int dy = t9 / 3, dx = t9 % 3;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          const f32x4 a = tile[(dz * IY + ty + dy) * ROW + q * XP + r + dx];
+          const f32x4 a = tile[((dz * IY + ty + dy) * IX + r + dx) * NQ + q];
           acc = fmaf(a.x, wv[t9][4 * q + 0], acc); acc = fmaf(a.y, wv[t9][4 * q + 1], acc);
           acc = fmaf(a.z, wv[t9][4 * q + 2], acc); acc = fmaf(a.w, wv[t9][4 * q + 3], acc);
         }
@@ -689,6 +819,9 @@ int launch_tiles(K kernel, const ConvParams& p, size_t lds, hipStream_t s, int m
       if (nconf < 48) configured[nconf++] = (const void*)kernel;
     }
   }
+  static int force_blocks = -1;                    // DSM_CONV_BLOCKS=N: persistent-grid A/B runs
+  if (force_blocks < 0) { const char* e = getenv("DSM_CONV_BLOCKS"); force_blocks = e ? atoi(e) : 0; }
+  if (force_blocks) max_blocks = force_blocks;
   int blocks = p.ntiles < max_blocks ? p.ntiles : max_blocks;
   if (blocks >= 8) blocks &= ~7;                 // whole rounds over the 8 XCDs
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(NTHREADS), lds, s, p);
@@ -703,7 +836,13 @@ int run_conv(ConvParams p, hipStream_t s) {
   const long nt = (long)p.B * p.Do * p.nty * p.ntx;
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
-  const size_t lds = (size_t)G::IZ * G::IY(TY) * (CK / 4) * G::XP * 16;
+  const size_t lds = (size_t)G::IZ * G::IY(TY) * (CK / 4) * G::IX * 16;
+  // stagger only pays on persistent multi-tile launches (each workgroup runs several chunks)
+  static int force_stagger = -2;                  // DSM_CONV_STAGGER=n: A/B runs (-1 = default)
+  if (force_stagger == -2) { const char* e = getenv("DSM_CONV_STAGGER"); force_stagger = e ? atoi(e) : -1; }
+  const int chunk_cycles = G::NTAP * (CK / 8) * 4 * TM * NT * 64;        // MFMA issue cycles per chunk
+  p.stagger = (p.ntiles >= 1024) ? (chunk_cycles / 2 + 4096) / 8192 : 0;
+  if (force_stagger >= 0) p.stagger = force_stagger;
   return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK, KZ, KXY, DIL>, p, lds, s, 512);
 }
 
@@ -714,7 +853,7 @@ int run_deconv(ConvParams p, hipStream_t s) {
   const long nt = (long)p.B * p.Di * p.nty * p.ntx * 2;       // x2: z-parity
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
-  const size_t lds = (size_t)2 * (TY + 1) * (CK / 4) * 34 * 16;
+  const size_t lds = (size_t)2 * (TY + 1) * (CK / 4) * 33 * 16;
   return launch_tiles(deconv3d_mfma_kernel<NT, CK>, p, lds, s, 512);
 }
 
@@ -807,7 +946,9 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
     return DSM_OK;
   }
   if (a->stride == 1) {
-    const int TM = (big && NT <= 2) ? 2 : 1;
+    static int force_tm = -1;                      // DSM_CONV3D_TM=1|2: tile-height A/B runs
+    if (force_tm < 0) { const char* e = getenv("DSM_CONV3D_TM"); force_tm = e ? atoi(e) : 0; }
+    const int TM = force_tm ? force_tm : ((big && NT <= 2) ? 2 : 1);
     *pl = Plan{0, 1, NT, TM, (NT == 2 && TM == 2) ? 8 : 16, 3, 3, 1};   // <1,2,2,16> would spill
   } else {
     *pl = Plan{0, 2, NT, 1, 8, 3, 3, 1};
@@ -843,7 +984,14 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   p.B = a->B; p.Cin = a->Cin; p.Cout = a->Cout;
   p.Di = a->Di; p.Hi = a->Hi; p.Wi = a->Wi; p.Do = a->Do; p.Ho = a->Ho; p.Wo = a->Wo;
   p.Dr = a->Dr; p.Hr = a->Hr; p.Wr = a->Wr; p.relu = a->relu;
-  p.ntx = p.nty = p.ntiles = 0;
+  p.ntx = p.nty = p.ntiles = 0; p.stagger = 0;
+  {
+    const unsigned long xb = 4ul * a->B * a->Di * a->Hi * a->Wi * a->Cin;
+    const int kd_ = a->kd ? a->kd : 3, k_ = a->k ? a->k : 3;
+    const unsigned long wb = 4ul * a->Cin * a->Cout * kd_ * k_ * k_;
+    DSM_REQUIRE(xb < (1ul << 32) && wb < (1ul << 32), DSM_ERR_UNSUPPORTED);   // 32-bit buffer offsets
+    p.xbytes = (unsigned)xb; p.wbytes = (unsigned)wb;
+  }
   hipStream_t s = (hipStream_t)stream;
   dsm_clear_stale_error();
   if (pl.kind == 3) {
@@ -854,7 +1002,7 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   if (pl.kind == 2) {
     p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, 8);
     p.ntiles = p.B * p.Do * p.nty * p.ntx;
-    const size_t lds = (size_t)3 * 10 * 2 * 34 * 16;              // CK = 8: 32.6 KB
+    const size_t lds = (size_t)3 * 10 * 34 * 2 * 16;              // CK = 8: 32.6 KB
     const int blocks = p.ntiles < 1024 ? p.ntiles : 1024;          // 4 workgroups per CU
     hipLaunchKernelGGL(conv3d_cout1_kernel<8>, dim3(blocks), dim3(NTHREADS), lds, s, p, p.w);
     return dsm_launch_status();
