@@ -106,7 +106,6 @@ struct ConvParams {
   int relu;
   int ntx, nty, ntiles;       // tile grid: x tiles, y tiles, total = B*Do*nty*ntx (x8 classes for deconv)
   unsigned xbytes, wbytes;    // extents of x and w for the buffer descriptors (< 4 GiB)
-  int stagger;                // units of s_sleep(127) (~8k cycles) for the odd wave slot; 0 = off
 };
 
 // XCD-aware persistent tile order: workgroups are dealt round-robin over the 8
@@ -133,11 +132,23 @@ __device__ __forceinline__ int first_tile(int ntiles, int& step, int& end) {
 //   y = acc*scale + shift (ReLU?) (+ skip) (ReLU?)
 // `yv` / `rv` point at this lane's voxel, channel 32*n + 4*h; XS = voxel stride between
 // consecutive lanes (1, or 2 for a transposed-conv parity class).
+// per-lane epilogue constants: scale/shift of the 16 channels this lane owns in one N-tile
+struct Affine { f32x4 sc[4], sh[4]; };
+__device__ __forceinline__ Affine load_affine(const float* __restrict__ scale,
+                                              const float* __restrict__ shift, int cbase) {
+  Affine a;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+    a.sc[g] = scale ? *reinterpret_cast<const f32x4*>(scale + cbase + 8 * g) : one;
+    a.sh[g] = shift ? *reinterpret_cast<const f32x4*>(shift + cbase + 8 * g) : zero;
+  }
+  return a;
+}
+
 template <int COUT>
-__device__ __forceinline__ void store_tile(const f32x16& acc, const float* __restrict__ scale,
-                                           const float* __restrict__ shift, int relu,
-                                           float* __restrict__ yv, const float* __restrict__ rv,
-                                           int cbase) {
+__device__ __forceinline__ void store_tile(const f32x16& acc, const Affine& af, int relu,
+                                           float* __restrict__ yv, const float* __restrict__ rv) {
   f32x4 r4[4];
   if (rv) {
 #pragma unroll
@@ -145,9 +156,7 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const float* __res
   }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (scale) sc = *reinterpret_cast<const f32x4*>(scale + cbase + 8 * g);
-    if (shift) sh = *reinterpret_cast<const f32x4*>(shift + cbase + 8 * g);
+    const f32x4 sc = af.sc[g], sh = af.sh[g];
     f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
     v = v * sc + sh;
     if (relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -308,31 +317,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
   auto commit = [&]() { stage_commit<NPF, NE>(tile, pf, tid); };
 
   f32x16 acc[TM][NT];
+  // folded BN of this lane's channels: kept in registers for the narrow variants (32 per
+  // N-tile), re-read per tile where the accumulators need the registers
+  constexpr bool KEEP_AFFINE = (NT * TM <= 2) && (NT == 1);
+  Affine af[KEEP_AFFINE ? NT : 1];
+  if constexpr (KEEP_AFFINE) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) af[n] = load_affine(p.scale, p.shift, n * 32 + 4 * h);
+  }
   const int lane_el = r * S * NQ + h;           // this lane's element within an image row
   int ck = 0;
   {
     const StageBox first = box_of(t, 0, true);
     stage_prefetch<NPF, NE, NQ, IX, IY>(pf, goff, first, xrsrc, tid);
   }
-  // Stagger.  The two workgroups resident on a CU run the same program on equal tiles and
-  // fall into lockstep: both stage / store at once (matrix pipe idle), then both multiply
-  // (sharing the pipe) -- period = N + 2M instead of 2M (stamps: multiply phase exactly 2x
-  // the single-wave time).  Delaying the wave in the odd hardware slot of its SIMD by about
-  // half a chunk, once, puts one workgroup's non-MFMA phases under the other's MFMAs.
-  // Placement-dependent for speed only (HW_REG_HW_ID wave_id), never for correctness.
-  if (p.stagger) {
-    const unsigned hw = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);   // HW_ID[3:0]
-    if (hw & 1u) {
-      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
   DSM_STAMP_INIT();
-  // Issue priority: a wave in its staging / epilogue phases competes for issue slots with the
-  // partner workgroup's MFMA stream and, being the younger or equal-priority wave, gets the
-  // leftovers (measured: 5k cycles of staging alone -> 15-19k beside a multiplying partner).
-  // An MFMA needs one issue slot per 64 cycles, so the multiply phase runs at priority 0 and
-  // everything else at 3.
-  __builtin_amdgcn_s_setprio(3);
   while (true) {
     __syncthreads();                            // every wave is done with the old chunk
     DSM_STAMP(0);                               // [0] wait at barrier 1
@@ -394,7 +393,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
     aload(std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
     DSM_STAMP(7);                               // [7] B/A ring prologue issue
-    __builtin_amdgcn_s_setprio(0);
     static_for<0, NITEM>([&](auto ic) {
       constexpr int item = decltype(ic)::value;
       if constexpr (item + AHEAD - 1 < NITEM) bload(std::integral_constant<int, item + AHEAD - 1>{});
@@ -421,7 +419,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
         }
       __builtin_amdgcn_sched_barrier(0);
     });
-    __builtin_amdgcn_s_setprio(3);
     DSM_STAMP(4);                               // [4] multiply (item loop)
     // ---- epilogue after the last chunk of a tile --------------------------------
     if (ck == nch - 1) {
@@ -437,8 +434,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const int cbase = n * 32 + 4 * h;
-          store_tile<COUT>(acc[m][n], p.scale, p.shift, p.relu, p.y + vox * COUT + cbase,
-                           p.res ? p.res + rvox * COUT + cbase : nullptr, cbase);
+          if constexpr (KEEP_AFFINE) {
+            store_tile<COUT>(acc[m][n], af[n], p.relu, p.y + vox * COUT + cbase,
+                             p.res ? p.res + rvox * COUT + cbase : nullptr);
+          } else {
+            const Affine a1 = load_affine(p.scale, p.shift, cbase);
+            store_tile<COUT>(acc[m][n], a1, p.relu, p.y + vox * COUT + cbase,
+                             p.res ? p.res + rvox * COUT + cbase : nullptr);
+          }
         }
       }
     }
@@ -517,28 +520,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
   stage_offsets<NPF, NE, NQ, IX, IY>(goff, tid, p.Hi, p.Wi, p.Cin);
   const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(p.x, p.xbytes);
   const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.wbytes);
-  auto prefetch = [&](int id, int ck) {
+  auto box_of = [&](int id, int ck, bool active) {
     id >>= 1;                                            // drop the z-parity bit
     const int xb = (id % p.ntx) * 32; id /= p.ntx;
     const int yb = (id % p.nty) * TY; id /= p.nty;
     const int zb = id % p.Di; const int b = id / p.Di;
-    const StageBox box = stage_box(p.x, b, zb, yb, xb, p.Di, p.Hi, p.Wi, p.Cin, ck * CK, IZ, IY,
-                                   IX, true);
-    stage_prefetch<NPF, NE, NQ, IX, IY>(pf, goff, box, xrsrc, tid);
+    return stage_box(p.x, b, zb, yb, xb, p.Di, p.Hi, p.Wi, p.Cin, ck * CK, IZ, IY, IX, active);
   };
   auto commit = [&]() { stage_commit<NPF, NE>(tile, pf, tid); };
 
   f32x16 acc[4][NT];                                     // class = py*2 + px
+  constexpr bool KEEP_AFFINE = (NT == 1);
+  Affine af[1];
+  if constexpr (KEEP_AFFINE) af[0] = load_affine(p.scale, p.shift, 4 * h);
   int ck = 0;
-  prefetch(t, 0);
-  __builtin_amdgcn_s_setprio(3);                         // see conv3d_mfma_kernel
+  {
+    const StageBox first = box_of(t, 0, true);
+    stage_prefetch<NPF, NE, NQ, IX, IY>(pf, goff, first, xrsrc, tid);
+  }
   while (true) {
     __syncthreads();
     commit();
     __syncthreads();
     int nt_ = t, nck = ck + 1;
     if (nck == nch) { nck = 0; nt_ = t + step; }
-    if (nt_ < end) prefetch(nt_, nck);
+    const StageBox nbox = box_of(nt_ < end ? nt_ : t, nck, nt_ < end);   // staged inside the loop
     if (ck == 0) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
@@ -593,6 +599,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
             if (nxt < NSTEP || pz) aload(std::integral_constant<int, nxt>{});
           }
         }
+        if constexpr (S2 < NPF)                            // next chunk's staged loads, one per step
+          pf[S2] = stage_load<S2, NE, NQ, IX, IY>(nbox, xrsrc, goff[S2], tid);
         __builtin_amdgcn_sched_barrier(0);
         constexpr int slot = deconv_aslot(S2, NG);
         constexpr int ring = S2 % AHEAD;
@@ -610,10 +618,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
       static_for<0, AHEAD - 1>(bload);                  // steps 0..AHEAD-2 are < NSTEP
       aload(std::integral_constant<int, 0>{});
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(0);
+      static_assert(NPF <= NSTEP, "staged loads must fit the first z tap");
       static_for<0, NSTEP>(body);
       if (pz) static_for<NSTEP, 2 * NSTEP>(body);
-      __builtin_amdgcn_s_setprio(3);
     }
     if (ck == nch - 1) {
       int id = t >> 1;
@@ -633,8 +640,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
             const int cbase = n * 32 + 4 * h;
-            store_tile<COUT>(acc[c][n], p.scale, p.shift, p.relu, p.y + vox * COUT + cbase,
-                             p.res ? p.res + rvox * COUT + cbase : nullptr, cbase);
+            if constexpr (KEEP_AFFINE) {
+              store_tile<COUT>(acc[c][n], af[0], p.relu, p.y + vox * COUT + cbase,
+                               p.res ? p.res + rvox * COUT + cbase : nullptr);
+            } else {
+              const Affine a1 = load_affine(p.scale, p.shift, cbase);
+              store_tile<COUT>(acc[c][n], a1, p.relu, p.y + vox * COUT + cbase,
+                               p.res ? p.res + rvox * COUT + cbase : nullptr);
+            }
           }
         }
       }
@@ -837,12 +850,6 @@ int run_conv(ConvParams p, hipStream_t s) {
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
   const size_t lds = (size_t)G::IZ * G::IY(TY) * (CK / 4) * G::IX * 16;
-  // stagger only pays on persistent multi-tile launches (each workgroup runs several chunks)
-  static int force_stagger = -2;                  // DSM_CONV_STAGGER=n: A/B runs (-1 = default)
-  if (force_stagger == -2) { const char* e = getenv("DSM_CONV_STAGGER"); force_stagger = e ? atoi(e) : -1; }
-  const int chunk_cycles = G::NTAP * (CK / 8) * 4 * TM * NT * 64;        // MFMA issue cycles per chunk
-  p.stagger = (p.ntiles >= 1024) ? (chunk_cycles / 2 + 4096) / 8192 : 0;
-  if (force_stagger >= 0) p.stagger = force_stagger;
   return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK, KZ, KXY, DIL>, p, lds, s, 512);
 }
 
@@ -984,7 +991,7 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   p.B = a->B; p.Cin = a->Cin; p.Cout = a->Cout;
   p.Di = a->Di; p.Hi = a->Hi; p.Wi = a->Wi; p.Do = a->Do; p.Ho = a->Ho; p.Wo = a->Wo;
   p.Dr = a->Dr; p.Hr = a->Hr; p.Wr = a->Wr; p.relu = a->relu;
-  p.ntx = p.nty = p.ntiles = 0; p.stagger = 0;
+  p.ntx = p.nty = p.ntiles = 0;
   {
     const unsigned long xb = 4ul * a->B * a->Di * a->Hi * a->Wi * a->Cin;
     const int kd_ = a->kd ? a->kd : 3, k_ = a->k ? a->k : 3;
