@@ -669,6 +669,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
 // Same persistent pipeline as the MFMA kernels: the next (tile, chunk) is prefetched into
 // registers while the current chunk is reduced; CK = 8 keeps the LDS image at 32 KB so that
 // four workgroups share a CU and hide each other's barriers.
+// Known limit (stamps + PMC, profiles/): the kernel is bound by L1/TA line traffic, not by
+// FMAs or LDS -- every 8-channel chunk touches 32 B of each 128-B voxel line, and each input
+// slice is re-read for three output planes (~3.6 GB of line traffic for a 189 MB input).  The
+// fix is a z-sliding form (one slice staged once as whole voxels, three rotating
+// accumulators); a first attempt was defeated by register allocation (loop-invariant weight
+// reads hoisted / scalar file exhausted) and is left for a later round.
 template <int CK>
 __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_kernel(ConvParams p,
                                                                    const float* __restrict__ w) {
@@ -701,13 +707,18 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_kernel(ConvParams p,
   float acc = 0.f;
   int ck = 0;
   prefetch(t, 0);
+  DSM_STAMP_INIT();
   while (true) {
     __syncthreads();
+    DSM_STAMP(0);
     stage_commit<NPF, NE>(tile, pf, tid);
+    DSM_STAMP(1);
     __syncthreads();
+    DSM_STAMP(2);
     int nt_ = t, nck = ck + 1;
     if (nck == nch) { nck = 0; nt_ = t + step; }
     if (nt_ < end) prefetch(nt_, nck);
+    DSM_STAMP(3);
     if (ck == 0) acc = 0.f;
     // Weights and activations both count on lgkmcnt, and scalar loads return out of order,
     // so mixing s_load with ds_read forces lgkmcnt(0) at every use.  Two pinned phases per
@@ -733,6 +744,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_kernel(ConvParams p,
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    DSM_STAMP(4);
     if (ck == nch - 1) {
       int id = t;
       const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
@@ -747,6 +759,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_kernel(ConvParams p,
         p.y[(((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo] = v;
       }
     }
+    DSM_STAMP(5);
     ck = nck; t = nt_;
     if (t >= end) break;
   }
