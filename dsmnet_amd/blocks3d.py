@@ -74,37 +74,44 @@ def _crop_add(y, residual):
 
 
 def _run_block_batch_stats(folded, conv, bn, x, residual, relu):
-    """Train-mode forward: the convolution on the HIP kernel, then BatchNorm with batch
-    statistics (running statistics updated as nn.BatchNorm3d does).  Forward only -- the
-    conv3d backward kernels are not in this build, so this path refuses to record
-    autograd history; it exists for BN calibration passes and forward parity."""
-    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
-        raise NotImplementedError(
-            "train-mode 3-D trunk is forward-only in this build (no conv3d backward "
-            "kernels yet): wrap the pass in torch.no_grad(), or call .eval()")
-    packed, _, _ = folded.get(conv, None)
-    bias = None if conv.bias is None else conv.bias.detach()
-    ones = None if bias is None else torch.ones_like(bias)
-    raw = cv.conv3d_block(x, packed, conv.out_channels, ones, bias, None, stride=conv.stride[0],
-                          transposed=isinstance(conv, nn.ConvTranspose3d), relu=RELU_NONE)
-    y = torch.nn.functional.batch_norm(raw, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+    """Train-mode block: convolution (forward, bwd-data and bwd-weight on the HIP kernels via
+    ``costvolume.Conv3dFunction``), then BatchNorm with batch statistics, skip add and ReLU as
+    stock torch ops (their autograd included) -- unfused, as training needs the pre-BN tensor."""
+    del folded
+    y = cv.conv3d(x, conv.weight, conv.bias, conv.stride[0], isinstance(conv, nn.ConvTranspose3d))
+    y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias,
                                        True, bn.momentum if bn.momentum is not None else 0.1,
                                        bn.eps)
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     if relu == RELU_BEFORE_ADD:
-        y = torch.relu_(y)
+        y = torch.relu(y)
     if residual is not None:
         y = _crop_add(y, residual)
     if relu == RELU_AFTER_ADD:
-        y = torch.relu_(y)
-    return y.contiguous(memory_format=torch.channels_last_3d)
+        y = torch.relu(y)
+    return y
 
 
 def run_block(folded, conv, bn, x, residual=None, relu=RELU_NONE):
     """conv (+ BN) (+ cropped skip) (+ ReLU); one launch in eval mode."""
     if bn is not None and bn.training:
         return _run_block_batch_stats(folded, conv, bn, x, residual, relu)
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        # autograd through a block without train-mode BN (bare convolutions such as classif*.2,
+        # or eval-mode BN while fine-tuning): unfused path with explicit gradients
+        y = cv.conv3d(x, conv.weight, conv.bias, conv.stride[0],
+                      isinstance(conv, nn.ConvTranspose3d))
+        if bn is not None:
+            y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight,
+                                               bn.bias, False, 0.0, bn.eps)
+        if relu == RELU_BEFORE_ADD:
+            y = torch.relu(y)
+        if residual is not None:
+            y = _crop_add(y, residual)
+        if relu == RELU_AFTER_ADD:
+            y = torch.relu(y)
+        return y
     packed, scale, shift = folded.get(conv, bn)
     return cv.conv3d_block(x, packed, conv.out_channels, scale, shift, residual,
                            stride=conv.stride[0],

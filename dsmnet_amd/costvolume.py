@@ -301,7 +301,7 @@ def conv3d_out_size(in_size, stride, transposed):
 
 
 def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, stride=1,
-                 transposed=False, relu=False):
+                 transposed=False, relu=False, out_size=None):
     """y = relu?(conv(x) * scale + shift (+ residual, cropped to the common size)).
 
     ``x`` is (B,Cin,D,H,W); it is consumed in NDHWC memory (converted if needed) and
@@ -320,6 +320,8 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
         residual = to_channels_last_3d(residual)
         a.Dr, a.Hr, a.Wr = residual.shape[2:]
         Do, Ho, Wo = min(Do, a.Dr), min(Ho, a.Hr), min(Wo, a.Wr)
+    if out_size is not None:                     # a corner of the natural output (bwd-data crops)
+        Do, Ho, Wo = (min(n, int(o)) for n, o in zip((Do, Ho, Wo), out_size))
     y = torch.empty((B, cout, Do, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=_CL3D)
     a.x, a.w_packed, a.y = x.data_ptr(), packed_weight.data_ptr(), y.data_ptr()
     a.scale = None if scale is None else scale.data_ptr()
@@ -401,3 +403,91 @@ def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
         rc = _lib.load().dsm_conv3d_fwd(ctypes.byref(a), _stream())
     _lib.check(rc, "dsm_conv3d_fwd")
     return y
+
+
+# ----------------------------------------------------------------------------
+# Conv3d / ConvTranspose3d (k=3) with autograd: training through the 3-D trunk
+# ----------------------------------------------------------------------------
+def _wgrad(x_cl, g_cl, cx, cg, stride):
+    """dW[g][c][tap] = sum_v X[v*stride + tap - 1][c] G[v][g]  ->  (cg, cx, 3, 3, 3)."""
+    B = x_cl.shape[0]
+    ws = torch.empty((cx // 32) * (cg // 32) * 27 * 1024, device=x_cl.device, dtype=torch.float32)
+    dw = torch.empty((cg, cx, 3, 3, 3), device=x_cl.device, dtype=torch.float32)
+    with torch.cuda.device(x_cl.device), _timed("conv3d_wgrad_kernel", 54.0 * cx * cg * B *
+                                                g_cl.shape[2] * g_cl.shape[3] * g_cl.shape[4]):
+        rc = _lib.load().dsm_conv3d_wgrad(_p(x_cl), _p(g_cl), _p(ws), _p(dw), B, cx, cg,
+                                          x_cl.shape[2], x_cl.shape[3], x_cl.shape[4],
+                                          g_cl.shape[2], g_cl.shape[3], g_cl.shape[4], stride,
+                                          _stream())
+    _lib.check(rc, "dsm_conv3d_wgrad")
+    return dw
+
+
+class Conv3dFunction(torch.autograd.Function):
+    """y = conv(x, weight) (+ bias) with k = 3, padding 1: ``nn.Conv3d(stride 1|2)`` or
+    ``nn.ConvTranspose3d(stride 2, output_padding 1)`` -- forward and both gradients on the
+    gfx950 kernels.  bwd-data is a convolution with re-packed weights on the forward kernels;
+    bwd-weight is ``dsm_conv3d_wgrad``.  In the reference this is autograd through nn.Conv3d."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, transposed):
+        _require_device("Conv3dFunction", x, weight, bias)
+        x = to_channels_last_3d(x)
+        cout = weight.shape[1] if transposed else weight.shape[0]
+        packed = pack_conv3d_weight(weight, transposed)
+        shift = None if bias is None else bias.detach().contiguous()
+        scale = None if bias is None else torch.ones_like(shift)
+        y = conv3d_block(x, packed, cout, scale, shift, None, stride, transposed, 0)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, transposed, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, transposed, has_bias = ctx.cfg
+        gy = to_channels_last_3d(gy)
+        B, cin = x.shape[0], x.shape[1]
+        cout = gy.shape[1]
+        dx = dw = db = None
+        w = weight.detach()
+        if cout == 1:                                   # classifier head, stride 1, not transposed
+            packed = pack_conv3d_weight(w, False)       # [27][Cin]
+            dwt = torch.empty(27 * cin, device=x.device, dtype=torch.float32)
+            dx = torch.empty_like(x)
+            with torch.cuda.device(x.device):
+                rc = _lib.load().dsm_conv3d_cout1_bwd(
+                    _p(x), _p(gy), _p(packed), _p(dx) if ctx.needs_input_grad[0] else None,
+                    _p(dwt) if ctx.needs_input_grad[1] else None, B, cin, x.shape[2], x.shape[3],
+                    x.shape[4], _stream())
+            _lib.check(rc, "dsm_conv3d_cout1_bwd")
+            if not ctx.needs_input_grad[0]:
+                dx = None
+            if ctx.needs_input_grad[1]:
+                dw = dwt.view(27, cin).t().contiguous().view(1, cin, 3, 3, 3)
+        else:
+            if ctx.needs_input_grad[0]:
+                if transposed:                          # dX = conv_s2(dY, W as (out=Cin, in=Cout))
+                    dx = conv3d_block(gy, pack_conv3d_weight(w, False), cin, stride=2,
+                                      out_size=x.shape[2:])
+                elif stride == 1:                       # dX = conv_s1(dY, flipped W^T)
+                    wt = w.flip(2, 3, 4).transpose(0, 1).contiguous()
+                    dx = conv3d_block(gy, pack_conv3d_weight(wt, False), cin, stride=1)
+                else:                                   # dX = convT_s2(dY, W), cropped to x
+                    dx = conv3d_block(gy, pack_conv3d_weight(w, True), cin, stride=2,
+                                      transposed=True, out_size=x.shape[2:])
+                if tuple(dx.shape) != tuple(x.shape):
+                    raise RuntimeError("Conv3dFunction.backward: dX shape %s != %s"
+                                       % (tuple(dx.shape), tuple(x.shape)))
+            if ctx.needs_input_grad[1]:
+                if transposed:                          # roles swapped: X := dY, G := x
+                    dw = _wgrad(gy, x, cout, cin, 2)    # (Cin, Cout, 3,3,3)
+                else:
+                    dw = _wgrad(x, gy, cin, cout, stride)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = gy.sum(dim=(0, 2, 3, 4))
+        return dx, dw, db, None, None
+
+
+def conv3d(x, weight, bias=None, stride=1, transposed=False):
+    return Conv3dFunction.apply(x, weight, bias, int(stride), bool(transposed))

@@ -290,7 +290,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nch = p.Cin / CK;
-  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(p.w);
 
   int step, end;
   int t = first_tile(p.ntiles, step, end);
@@ -499,7 +498,7 @@ __host__ __device__ constexpr int deconv_next_fresh(int S2, int NG) {
 template <int NT, int CK>
 __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p) {
   constexpr int TY = 4;
-  constexpr int IZ = 2, IY = TY + 1, IX = 33, XP = 34;
+  constexpr int IZ = 2, IY = TY + 1, IX = 33;
   constexpr int NQ = CK / 4, NG = CK / 8;
   constexpr int NE = IZ * IY * IX * NQ;
   constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
@@ -508,7 +507,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nch = p.Cin / CK;
-  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(p.w);
   const int lane_el = r * NQ + h;                        // element within an image row
 
   int step, end;
@@ -679,7 +677,7 @@ template <int CK>
 __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_kernel(ConvParams p,
                                                                    const float* __restrict__ w) {
   constexpr int TY = 8;
-  constexpr int IY = TY + 2, IX = 34, XP = 34, IZ = 3;
+  constexpr int IY = TY + 2, IX = 34, IZ = 3;
   constexpr int NQ = CK / 4;
   constexpr int NE = IZ * IY * IX * NQ;
   constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;

@@ -1,0 +1,261 @@
+// Backward kernels of the k=3 3-D convolution blocks (training through the trunk).
+//
+// bwd-data needs no kernel of its own: it is a convolution again and runs on
+// conv3d_mfma_kernel / deconv3d_mfma_kernel with re-packed weights (host side,
+// dsmnet_amd/costvolume.py):
+//   conv stride 1  : dX = conv_s1(dY, W^T flipped)
+//   conv stride 2  : dX = convT_s2(dY, W)            (cropped to the input size)
+//   convT stride 2 : dX = conv_s2(dY, W)
+// This file holds bwd-weight (a voxel-reduction GEMM on fp32 MFMA) and the two small
+// Cout = 1 kernels (classifier heads).
+//
+// bwd-weight:  dW[g][c][tap] = sum_v X[v*S + tap - 1][c] * G[v][g]
+//   X: the layer input (halo'd, channels c), G: dY (channels g); for a transposed conv the
+//   caller swaps the roles (X := dY, G := x) and gets the ConvTranspose3d layout directly.
+// GEMM view per tap: M = 32 X-channels, N = 32 G-channels, K = voxels.  v_mfma_f32_32x32x2_f32
+// consumes two voxels per instruction: A[i=c][k] = X[voxel_k + tap][c], B[k][j=g] = G[voxel_k][g]
+// -- both are one ds_read_b32 per lane with immediate offsets (no VALU: the fp32 MFMA shares
+// the vector ALU, see conv3d.hip).  A workgroup owns one (c-tile, g-tile) pair and a set of
+// output tiles; wave w owns taps {w, w+4, ...} (<= 7 accumulators); partial sums leave as
+// fp32 atomics into a [pair][tap][c][g] workspace (g contiguous: 128-B segments), which a last
+// small kernel permutes into torch's (G, C, 3, 3, 3).
+#include "common.hpp"
+#include <type_traits>
+
+namespace {
+constexpr int NT_ = 256;
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+
+struct WgradParams {
+  const float* x; const float* g; float* ws;      // ws: [npair][27][32][32]
+  int B, Cx, Cg;                                   // channels of X and G
+  int Dx, Hx, Wx;                                  // X volume
+  int Dg, Hg, Wg;                                  // G volume (the strided side)
+  int ntx, nty, ntiles, npair;
+};
+
+// S: stride of X relative to G.  Tile: 1 z x TY rows x 32 columns of G voxels.
+template <int S, int TY>
+__global__ __launch_bounds__(NT_, 1) void conv3d_wgrad_kernel(WgradParams p) {
+  constexpr int IY = (TY - 1) * S + 3, IX = 31 * S + 3, IZ = 3;
+  constexpr int NXE = IZ * IY * IX * 8;            // X tile: 32 channels = 8 x 16 B per voxel
+  constexpr int NGE = TY * 32 * 8;                 // G tile
+  constexpr int NPX = (NXE + NT_ - 1) / NT_, NPG = (NGE + NT_ - 1) / NT_;
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+  f32x4* xt = lds;                                 // [z][y][x][8]
+  f32x4* gt = lds + NXE;                           // [y][x][8]
+  const float* xf = reinterpret_cast<const float*>(xt);
+  const float* gf = reinterpret_cast<const float*>(gt);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int pair = blockIdx.y;
+  const int ct = pair / (p.Cg / 32), gtile = pair % (p.Cg / 32);   // X-channel tile, G-channel tile
+  f32x16 acc[7];
+#pragma unroll
+  for (int a = 0; a < 7; ++a)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+
+  for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+    int id = t;
+    const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
+    const int ty0 = (id % p.nty) * TY; id /= p.nty;
+    const int tz = id % p.Dg; const int b = id / p.Dg;
+    __syncthreads();
+    // stage X halo tile (zeros outside the volume) and G tile (zeros outside)
+    for (int k = 0; k < NPX; ++k) {
+      const int e = tid + k * NT_;
+      if (e < NXE) {
+        const int q = e & 7, v = e >> 3;
+        const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
+        const int zi = tz * S - 1 + zz, yi = ty0 * S - 1 + yy, xi = tx0 * S - 1 + xx;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (zi >= 0 && zi < p.Dx && yi >= 0 && yi < p.Hx && xi >= 0 && xi < p.Wx)
+          val = *reinterpret_cast<const f32x4*>(
+              p.x + ((((long)b * p.Dx + zi) * p.Hx + yi) * p.Wx + xi) * p.Cx + ct * 32 + q * 4);
+        xt[e] = val;
+      }
+    }
+    for (int k = 0; k < NPG; ++k) {
+      const int e = tid + k * NT_;
+      if (e < NGE) {
+        const int q = e & 7, v = e >> 3;
+        const int xx = v & 31, yy = v >> 5;
+        const int yi = ty0 + yy, xi = tx0 + xx;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (yi < p.Hg && xi < p.Wg)
+          val = *reinterpret_cast<const f32x4*>(
+              p.g + ((((long)b * p.Dg + tz) * p.Hg + yi) * p.Wg + xi) * p.Cg + gtile * 32 + q * 4);
+        gt[e] = val;
+      }
+    }
+    __syncthreads();
+    // wave w: taps w, w+4, ...; per tap K = TY*32 voxels, two per MFMA (k = h)
+    sfor<0, 7>([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      const int tap = wave + 4 * a;
+      if (tap < 27) {
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        const float* xa = xf + ((dz * IY + dy) * IX + dx) * 32 + r;       // + voxel*32*S...
+#pragma unroll 4
+        for (int kk = 0; kk < TY * 16; ++kk) {
+          const int vy = kk >> 4, vx = ((kk & 15) << 1) + h;              // voxel of this lane's k
+          const float av = xa[((vy * S) * IX + vx * S) * 32];
+          const float bv = gf[(vy * 32 + vx) * 32 + r];
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
+        }
+      }
+    });
+  }
+  // flush: ws[pair][tap][c][g] += acc  (row = c, column = g on the lanes)
+  sfor<0, 7>([&](auto ac) {
+    constexpr int a = decltype(ac)::value;
+    const int tap = wave + 4 * a;
+    if (tap < 27) {
+      float* dst = p.ws + (((long)pair * 27 + tap) * 32) * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = (i & 3) + 8 * (i >> 2) + 4 * h;
+        atomicAdd(dst + c * 32, acc[a][i]);
+      }
+    }
+  });
+}
+
+// ws [pair = ct*(Cg/32)+gt][tap][c][g]  ->  dW[g_abs][c_abs][tap]   (torch (G, C, 3,3,3))
+__global__ void wgrad_permute_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cx,
+                                     int Cg) {
+  const long n = (long)Cx * Cg * 27;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int tap = i % 27;
+  const int c = (i / 27) % Cx;
+  const int g = i / (27L * Cx);
+  const int pair = (c / 32) * (Cg / 32) + g / 32;
+  dw[i] = ws[(((long)pair * 27 + tap) * 32 + (c & 31)) * 32 + (g & 31)];
+}
+
+// ---- Cout = 1 (classifier heads): y[v] = sum_tap sum_c x[v+tap-1][c] w[tap][c] ------------
+// bwd-data: dx[u][c] = sum_tap g[u - tap + 1] * w[tap][c];  thread = (voxel, 4 channels)
+__global__ __launch_bounds__(256) void cout1_bwd_data_kernel(const float* __restrict__ g,
+                                                             const float* __restrict__ w,  // [27][C]
+                                                             float* __restrict__ dx, int B, int C,
+                                                             int D, int H, int W) {
+  const long n = (long)B * D * H * W * (C / 4);
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int q = i % (C / 4);
+  long v = i / (C / 4);
+  const int x = v % W; v /= W;
+  const int y = v % H; v /= H;
+  const int z = v % D; const int b = v / D;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int tap = 0; tap < 27; ++tap) {
+    const int zz = z - tap / 9 + 1, yy = y - (tap / 3) % 3 + 1, xx = x - tap % 3 + 1;
+    if (zz < 0 || zz >= D || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+    const float gv = g[(((long)b * D + zz) * H + yy) * W + xx];
+    a += gv * *reinterpret_cast<const f32x4*>(w + tap * C + q * 4);
+  }
+  *reinterpret_cast<f32x4*>(dx + i * 4) = a;
+}
+
+// bwd-weight: dw[tap][c] = sum_v x[v+tap-1][c] g[v];  block = one (b, z, y) row, lanes over c,
+// partial sums per block leave as atomics into dw (27*C floats).
+__global__ __launch_bounds__(256) void cout1_bwd_weight_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ g,
+                                                               float* __restrict__ dw, int B, int C,
+                                                               int D, int H, int W) {
+  // thread = (tap-group, channel): 256 threads cover 27 taps x C<=... in passes
+  const int row = blockIdx.x;                      // (b*D + z)*H + y
+  const int y = row % H; const int z = (row / H) % D; const int b = row / (H * D);
+  const float* grow = g + (long)row * W;
+  for (int u = threadIdx.x; u < 27 * C; u += 256) {
+    const int tap = u / C, c = u % C;
+    const int zz = z + tap / 9 - 1, yy = y + (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+    if (zz < 0 || zz >= D || yy < 0 || yy >= H) continue;
+    const float* xrow = x + ((((long)b * D + zz) * H + yy) * W) * C + c;
+    float a = 0.f;
+    const int x_lo = dx < 0 ? 1 : 0, x_hi = dx > 0 ? W - 1 : W;
+    for (int xx = x_lo; xx < x_hi; ++xx) a = fmaf(xrow[(long)(xx + dx) * C], grow[xx], a);
+    atomicAdd(dw + u, a);
+  }
+}
+
+}  // namespace
+
+// x: (B,Dx,Hx,Wx,Cx) NDHWC; g: (B,Dg,Hg,Wg,Cg); stride: X positions per G position (1 or 2);
+// ws: workspace of (Cx/32)*(Cg/32)*27*32*32 floats (zeroed here); dw: (Cg, Cx, 27), overwritten.
+extern "C" int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, int Cx,
+                                int Cg, int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int stride,
+                                dsm_stream_t stream) {
+  DSM_REQUIRE(x && g && ws && dw, DSM_ERR_ARG);
+  DSM_REQUIRE(B > 0 && Cx > 0 && Cg > 0 && Dx > 0 && Hx > 0 && Wx > 0 && Dg > 0 && Hg > 0 && Wg > 0,
+              DSM_ERR_ARG);
+  DSM_REQUIRE(stride == 1 || stride == 2, DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(Cx % 32 == 0 && Cg % 32 == 0, DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(dsm_aligned16(x) && dsm_aligned16(g), DSM_ERR_ALIGN);
+  hipStream_t s = (hipStream_t)stream;
+  dsm_clear_stale_error();
+  WgradParams p;
+  p.x = (const float*)x; p.g = (const float*)g; p.ws = (float*)ws;
+  p.B = B; p.Cx = Cx; p.Cg = Cg; p.Dx = Dx; p.Hx = Hx; p.Wx = Wx; p.Dg = Dg; p.Hg = Hg; p.Wg = Wg;
+  p.npair = (Cx / 32) * (Cg / 32);
+  const size_t wsbytes = (size_t)p.npair * 27 * 32 * 32 * sizeof(float);
+  if (hipMemsetAsync(ws, 0, wsbytes, s) != hipSuccess) return DSM_ERR_LAUNCH;
+  constexpr int TY1 = 4, TY2 = 2;
+  const int TY = stride == 1 ? TY1 : TY2;
+  p.ntx = dsm_cdiv(Wg, 32); p.nty = dsm_cdiv(Hg, TY);
+  const long nt = (long)B * Dg * p.nty * p.ntx;
+  DSM_REQUIRE(nt < (1L << 30), DSM_ERR_UNSUPPORTED);
+  p.ntiles = (int)nt;
+  int bx = 256 / p.npair; if (bx < 1) bx = 1;
+  if (bx > p.ntiles) bx = p.ntiles;
+  dim3 grid(bx, p.npair);
+  if (stride == 1) {
+    const size_t lds = (size_t)(3 * (TY1 + 2) * 34 * 8 + TY1 * 32 * 8) * 16;
+    if (hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<1, TY1>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return DSM_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv3d_wgrad_kernel<1, TY1>), grid, dim3(NT_), lds, s, p);
+  } else {
+    const size_t lds = (size_t)(3 * ((TY2 - 1) * 2 + 3) * 65 * 8 + TY2 * 32 * 8) * 16;
+    if (hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<2, TY2>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return DSM_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv3d_wgrad_kernel<2, TY2>), grid, dim3(NT_), lds, s, p);
+  }
+  const long n = (long)Cx * Cg * 27;
+  hipLaunchKernelGGL(wgrad_permute_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s,
+                     (const float*)ws, (float*)dw, Cx, Cg);
+  return dsm_launch_status();
+}
+
+// Cout = 1 convolution (stride 1): g: (B,D,H,W); x: (B,D,H,W,C); w_packed: [27][C] (as packed
+// by dsm_conv3d_pack_weights); dx: (B,D,H,W,C) or NULL; dw: (1, C, 27) torch layout or NULL.
+extern "C" int dsm_conv3d_cout1_bwd(const void* x, const void* g, const void* w_packed, void* dx,
+                                    void* dw_tapmajor, int B, int C, int D, int H, int W,
+                                    dsm_stream_t stream) {
+  DSM_REQUIRE(g && (dx || dw_tapmajor), DSM_ERR_ARG);
+  DSM_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && D > 0 && H > 0 && W > 0, DSM_ERR_ARG);
+  DSM_REQUIRE((long)B * D * H <= 0x7fffffffL, DSM_ERR_UNSUPPORTED);
+  hipStream_t s = (hipStream_t)stream;
+  dsm_clear_stale_error();
+  if (dx) {
+    DSM_REQUIRE(w_packed, DSM_ERR_ARG);
+    const long n = (long)B * D * H * W * (C / 4);
+    hipLaunchKernelGGL(cout1_bwd_data_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s,
+                       (const float*)g, (const float*)w_packed, (float*)dx, B, C, D, H, W);
+  }
+  if (dw_tapmajor) {
+    DSM_REQUIRE(x, DSM_ERR_ARG);
+    if (hipMemsetAsync(dw_tapmajor, 0, (size_t)27 * C * sizeof(float), s) != hipSuccess)
+      return DSM_ERR_LAUNCH;
+    hipLaunchKernelGGL(cout1_bwd_weight_kernel, dim3(B * D * H), dim3(256), 0, s, (const float*)x,
+                       (const float*)g, (float*)dw_tapmajor, B, C, D, H, W);
+  }
+  return dsm_launch_status();
+}

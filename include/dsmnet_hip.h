@@ -166,6 +166,28 @@ int dsm_conv3d_fwd(const dsm_conv3d_args* args, dsm_stream_t stream);
  * used by bench.py to attribute per-launch timings.  No launch, no device access. */
 int dsm_conv3d_plan(const dsm_conv3d_args* args, char* buf, int len);
 
+/* ---------------------------------------------------------------------------
+ * Backward of the 3-D convolution blocks (training through the trunk; in the reference this
+ * is autograd through nn.Conv3d / nn.ConvTranspose3d).  bwd-data is a convolution again and
+ * runs on dsm_conv3d_fwd with re-packed weights (see dsmnet_amd/costvolume.py); these are the
+ * bwd-weight entry points.
+ *   dW[g][c][tap] = sum_v X[v*stride + tap - 1][c] * G[v][g]
+ * x: (B,Dx,Hx,Wx,Cx) NDHWC, the strided-over side; g: (B,Dg,Hg,Wg,Cg) NDHWC.
+ *   Conv3d(stride s):      X = layer input, G = dY        -> dw is (Cout, Cin, 3,3,3)
+ *   ConvTranspose3d(s=2):  X = dY, G = layer input, stride 2 -> dw is (Cin, Cout, 3,3,3)
+ * ws: scratch of (Cx/32)*(Cg/32)*27*1024 floats; dw: Cg*Cx*27 floats, overwritten.
+ * Channels must be multiples of 32.  Sums are accumulated with fp32 atomics (order varies).
+ * ------------------------------------------------------------------------- */
+int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, int Cx, int Cg,
+                     int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int stride,
+                     dsm_stream_t stream);
+
+/* Cout = 1, stride 1 (classifier heads): g (B,D,H,W); x (B,D,H,W,C); w_packed [27][C];
+ * dx (B,D,H,W,C) or NULL; dw_tapmajor [27][C] or NULL (the caller transposes to (1,C,27)). */
+int dsm_conv3d_cout1_bwd(const void* x, const void* g, const void* w_packed, void* dx,
+                         void* dw_tapmajor, int B, int C, int D, int H, int W,
+                         dsm_stream_t stream);
+
 /* NCDHW <-> NDHWC repack of an fp32 volume (used at the boundary with stock
  * torch modules that want contiguous NCDHW). to_ndhwc = 1: src NCDHW. */
 int dsm_volume_relayout(const void* src, void* dst, int B, int C, int D, int H, int W,

@@ -55,7 +55,7 @@ def test_psmnet_end_to_end_256x512(hip_lib, golden_e2e):
 
 def test_psmnet_train_mode_forward_vs_golden(hip_lib, golden_blocks):
     """Train-mode BN (batch statistics) forward: HIP convolution + BatchNorm3d with batch
-    stats, against the reference's train-mode goldens; recording autograd is refused."""
+    stats, against the reference's train-mode goldens (gradients: test_conv3d_bwd_gpu.py)."""
     meta = golden_blocks.meta["blocks"]
     sd = randomise_bn(OM.init_state("psmnet", meta["psm_state_seed"]), meta["psm_bn_seed"])
     from dsmnet_amd.models import model_create_by_name
@@ -71,8 +71,8 @@ def test_psmnet_train_mode_forward_vs_golden(hip_lib, golden_blocks):
     golden_blocks.compare("block3d.psm.train.hg1.out", o1, 5e-4)
     golden_blocks.compare("block3d.psm.train.hg1.post", post1, 5e-4)
     assert int(m.dres0[0][1].num_batches_tracked) == 1
-    with pytest.raises(NotImplementedError):
-        m.dres0(x64)                                   # grad mode on: refused
+    y = m.dres0(x64)                                   # grad mode on: autograd graph recorded
+    assert y.requires_grad
 
 
 def test_gcnet_end_to_end_64x128(hip_lib, golden_e2e):
