@@ -88,3 +88,38 @@ def test_psmnet_trunk_training_step_vs_oracle(hip_lib):
         assert maxerr(g, r) <= tol, "%s: %.3e > %.3e" % (k, maxerr(g, r), tol)
     # running statistics were updated as nn.BatchNorm3d does
     assert maxerr(m.dres0[0][1].running_mean, osd["dres0.0.1.running_mean"]) <= 1e-4
+
+
+def test_psmnet_full_training_step(hip_lib):
+    """BASELINE config #5 in miniature (fp32, 1 GPU): PSMNet in train mode, 256x512, D=192:
+    forward with batch-statistics BN, smooth-L1 loss on the three heads, backward through the
+    HIP trunk and the stock-torch towers, one SGD step; every parameter receives a finite
+    gradient and the loss on the same pair goes down."""
+    from dsmnet_amd import sharding
+    from dsmnet_amd.models import model_create_by_name
+    torch.manual_seed(0)
+    m = model_create_by_name("psmnet", 192).cuda().train()
+    for i in (1, 2, 3):                                   # sane logit scale for a random init
+        getattr(m, "classif%d" % i)[2].weight.data.mul_(1e-3)
+    g = torch.Generator().manual_seed(5)
+    left = torch.rand(1, 3, 256, 512, generator=g).cuda()
+    right = torch.roll(left, -6, dims=3)
+    target = torch.full((1, 256, 512), 6.0, device="cuda")
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+
+    def step():
+        opt.zero_grad()
+        _, preds = m(left, right)
+        loss = sum(w * F.smooth_l1_loss(p, target) for w, p in zip((1.0, 0.7, 0.5), preds))
+        loss.backward()
+        return loss
+
+    l0 = step()
+    missing = [n for n, p in m.named_parameters() if p.grad is None]
+    assert not missing, missing[:5]
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    assert sharding.allreduce_gradients(m.parameters(), world=1) == 0    # single process: no-op
+    opt.step()
+    l1 = step()
+    assert torch.isfinite(l0) and torch.isfinite(l1)
+    assert l1.item() < l0.item(), (l0.item(), l1.item())
