@@ -954,7 +954,7 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   // else 4 rows.  Stride 2 stages 8 channels per chunk so that two workgroups fit a CU.
   if (a->transposed) {
     DSM_REQUIRE(NT <= 2, DSM_ERR_UNSUPPORTED);   // 4 classes x NT accumulators must fit 256 VGPRs
-    *pl = Plan{1, 2, NT, 1, 16, 3, 3, 1};
+    *pl = Plan{1, 2, NT, 1, 16, 3, 3, 1};   // (32-channel chunks measured slower: 306 vs 283 us)
     return DSM_OK;
   }
   const bool big = (long)a->B * a->Do * dsm_cdiv(a->Ho, 8) * dsm_cdiv(a->Wo, 32) >= 1024;

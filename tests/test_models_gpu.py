@@ -130,3 +130,34 @@ def test_psmnet_540x960_crop_add(hip_lib):
     for g, r in zip(got, ref):
         assert g.shape == r.shape == (1, 1, 12, 17, 31)
         assert maxerr(g, r) <= 5e-4 * max(1.0, r.abs().max().item())
+
+
+def test_psmnet_kitti_shape_375x1242(hip_lib, golden_e2e):
+    """The reference's own timing shape (models/test_models_time.py:35: [1,3,375,1242]): odd
+    sizes at every level (94 -> 47 -> 24 -> 48 vs 47: myadd_3d crops), non-integer upsampling
+    ratios in H and W (generic soft-argmin kernel paths), against the oracle on the host CPU."""
+    sd, _ = golden_state(golden_e2e, "psmnet")
+    imL, imR = images(77, 375, 1242)
+    m = load("psmnet", sd)
+    with torch.no_grad():
+        _, preds = m(imL.cuda(), imR.cuda())
+        ref = OM.forward("psmnet", sd, imL, imR)
+    for p, r in zip(preds, ref):
+        assert p.shape == r.shape == (1, 375, 1242)
+        assert maxerr(p, r) <= DISP_TOL
+
+
+def test_psmnet_batch_of_two(hip_lib, golden_e2e):
+    """B = 2: each pair of a batch equals the same pair run alone (pairs are independent --
+    the property the multi-GPU sharding relies on)."""
+    sd, cfg = golden_state(golden_e2e, "psmnet")
+    a = images(cfg["image_seed"], *cfg["hw"])
+    b = images(91, *cfg["hw"])
+    m = load("psmnet", sd)
+    with torch.no_grad():
+        both = m(torch.cat([a[0], b[0]]).cuda(), torch.cat([a[1], b[1]]).cuda())[1]
+        one = m(b[0].cuda(), b[1].cuda())[1]
+    for pb, po in zip(both, one):
+        assert pb.shape == (2, 256, 512)
+        assert maxerr(pb[1:], po) <= 1e-4
+    golden_e2e.compare("e2e.psmnet.pred3", both[0][:1], DISP_TOL)
