@@ -34,6 +34,7 @@ H, W, MAXDISP = 384, 1280, 192
 # MI355X ceilings (/opt/skills/guides/MI355X_MICROARCH.md): HBM3E 8.0 TB/s spec, fp32-input
 # MFMA 157.3 TFLOP/s dense (v_mfma_f32_32x32x2_f32; no xf32/TF32 on gfx950)
 PEAK_HBM_GBS = 8000.0
+HBM_COPY_CEILING_GBS = 6290.0      # measured float4 copy (same guide); reported beside the spec fraction
 PEAK_F32_MFMA_TFLOPS = 157.3
 
 
@@ -68,6 +69,7 @@ def kernel_rooflines(summary, steps):
             achieved, peak, unit, bound = per_launch / avg_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
         out[name] = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
                      "frac": round(achieved / peak, 4), "traffic": traffic.get(name),
+                     "frac_of_copy_ceiling": None if mfma else round(achieved / HBM_COPY_CEILING_GBS, 4),
                      "launches_per_step": n / steps, "avg_launch_us": round(avg_s * 1e6, 2),
                      "ms_per_step": round(ms / steps, 4),
                      "work_per_launch": per_launch}

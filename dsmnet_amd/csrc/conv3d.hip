@@ -763,42 +763,76 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_kernel(ConvParams p,
   }
 }
 
-// ConvTranspose3d(k3,s2,p1,op1) to one channel (GCNet l37, models/gcnet.py:63,100):
-// thread per output voxel, gathers its 1..8 input voxels straight from L2.
+// ConvTranspose3d(k3,s2,p1,op1) to one channel (GCNet l37, models/gcnet.py:63,100), Cin = 32.
+// LDS-tiled: a workgroup stages the (2 x 5 x 33)-voxel input box of a 4 x 32 tile of input-grid
+// positions (whole 128-B voxels, element order) plus the 27 x 32 weights; thread
+// (position, z-parity) produces the four (y, x)-parity outputs of that z-parity: every staged
+// voxel quad is read once per thread and used for all the taps it feeds; weights are LDS
+// broadcasts.  (The first version -- one thread per output voxel gathering 1..8 voxels from
+// L2 with 128-B-strided lanes -- ran at 0.23 TB/s: 2.2 ms for GCNet's 100 MB output.)
 __global__ __launch_bounds__(NTHREADS) void deconv3d_cout1_kernel(ConvParams p) {
-  const int xo = blockIdx.x * NTHREADS + threadIdx.x;
-  const int yo = blockIdx.y;
-  const int zo = blockIdx.z % p.Do, b = blockIdx.z / p.Do;
-  if (xo >= p.Wo) return;
-  float acc = 0.f;
-  const int pz = zo & 1, py = yo & 1, px = xo & 1;
-  const int mz = zo >> 1, my = yo >> 1, mx = xo >> 1;
+  constexpr int TY = 4, IZ = 2, IY = TY + 1, IX = 33, NQ = 8;
+  constexpr int NE = IZ * IY * IX * NQ;                // 2640
+  constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;  // 11
+  extern __shared__ __attribute__((aligned(16))) f32x4 tile[];   // box, then weights [27][8]
+  f32x4* wl = tile + NE;
+  const int tid = threadIdx.x;
+  int id = blockIdx.x;
+  const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
+  const int ty0 = (id % p.nty) * TY; id /= p.nty;
+  const int tz = id % p.Di; const int b = id / p.Di;
+  unsigned goff[NPF];
+  stage_offsets<NPF, NE, NQ, IX, IY>(goff, tid, p.Hi, p.Wi, p.Cin);
+  const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(p.x, p.xbytes);
+  const StageBox box = stage_box(p.x, b, tz, ty0, tx0, p.Di, p.Hi, p.Wi, p.Cin, 0, IZ, IY, IX, true);
+  f32x4 pf[NPF];
+  stage_prefetch<NPF, NE, NQ, IX, IY>(pf, goff, box, xrsrc, tid);
+  for (int i = tid; i < 27 * NQ; i += NTHREADS) wl[i] = reinterpret_cast<const f32x4*>(p.w)[i];
+  stage_commit<NPF, NE>(tile, pf, tid);
+  __syncthreads();
+  // thread -> (x position r, row ty, z-parity pz); pz is wave-uniform (waves 0-1: 0, 2-3: 1)
+  const int r = tid & 31, ty = (tid >> 5) & 3, pz = tid >> 7;
+  const int zo = 2 * tz + pz;
+  if (zo >= p.Do) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};                 // class = py*2 + px
   for (int iz = 0; iz <= pz; ++iz) {
-    const int zi = mz + iz, kz = pz ? (iz ? 0 : 2) : 1;
-    if (zi >= p.Di) continue;
-    for (int iy = 0; iy <= py; ++iy) {
-      const int yi = my + iy, ky = py ? (iy ? 0 : 2) : 1;
-      if (yi >= p.Hi) continue;
-      for (int ix = 0; ix <= px; ++ix) {
-        const int xi = mx + ix, kx = px ? (ix ? 0 : 2) : 1;
-        if (xi >= p.Wi) continue;
-        const int tap = (kz * 3 + ky) * 3 + kx;
-        const f32x4* a = reinterpret_cast<const f32x4*>(
-            p.x + ((((long)b * p.Di + zi) * p.Hi + yi) * p.Wi + xi) * p.Cin);
-        const f32x4* w = reinterpret_cast<const f32x4*>(p.w + (long)tap * p.Cin);
-        for (int c = 0; c < p.Cin / 4; ++c) {
-          const f32x4 av = a[c], wv = w[c];
-          acc = fmaf(av.x, wv.x, acc); acc = fmaf(av.y, wv.y, acc);
-          acc = fmaf(av.z, wv.z, acc); acc = fmaf(av.w, wv.w, acc);
+    const int kz = pz ? (iz ? 0 : 2) : 1;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {                      // input offset (iy, ix)
+      const int iy = o >> 1, ix = o & 1;
+      f32x4 v[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) v[q] = tile[((iz * IY + ty + iy) * IX + r + ix) * NQ + q];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {                    // classes fed by this offset
+        const int py = c >> 1, px = c & 1;
+        if (iy > py || ix > px) continue;
+        const int ky = py ? (iy ? 0 : 2) : 1, kx = px ? (ix ? 0 : 2) : 1;
+        const f32x4* wt = wl + ((kz * 3 + ky) * 3 + kx) * NQ;
+        float a = acc[c];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const f32x4 w4 = wt[q];
+          a = fmaf(v[q].x, w4.x, a); a = fmaf(v[q].y, w4.y, a);
+          a = fmaf(v[q].z, w4.z, a); a = fmaf(v[q].w, w4.w, a);
         }
+        acc[c] = a;
       }
     }
   }
-  float v = acc * (p.scale ? p.scale[0] : 1.f) + (p.shift ? p.shift[0] : 0.f);
-  if (p.relu == 2) v = fmaxf(v, 0.f);
-  if (p.res) v += p.res[(((long)b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo];
-  if (p.relu == 1) v = fmaxf(v, 0.f);
-  p.y[(((long)b * p.Do + zo) * p.Ho + yo) * p.Wo + xo] = v;
+  const int ym = ty0 + ty, xm = tx0 + r;
+  if (ym >= p.Hi || xm >= p.Wi) return;
+  const float sc = p.scale ? p.scale[0] : 1.f, sh = p.shift ? p.shift[0] : 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int yo = 2 * ym + (c >> 1), xo = 2 * xm + (c & 1);
+    if (yo >= p.Ho || xo >= p.Wo) continue;
+    float v = acc[c] * sc + sh;
+    if (p.relu == 2) v = fmaxf(v, 0.f);
+    if (p.res) v += p.res[(((long)b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo];
+    if (p.relu == 1) v = fmaxf(v, 0.f);
+    p.y[(((long)b * p.Do + zo) * p.Ho + yo) * p.Wo + xo] = v;
+  }
 }
 
 // ----------------------------------------------------------------------------
@@ -940,7 +974,7 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
     DSM_REQUIRE(a->Dr >= a->Do && a->Hr >= a->Ho && a->Wr >= a->Wo, DSM_ERR_ARG);
   if (a->Cout == 1) {
     if (a->transposed) {
-      DSM_REQUIRE(a->Ho <= 65535 && (long)a->B * a->Do <= 65535, DSM_ERR_UNSUPPORTED);
+      DSM_REQUIRE(a->Cin == 32, DSM_ERR_UNSUPPORTED);      // GCNet l37 (staged as whole voxels)
       *pl = Plan{3, 2, 0, 0, 0, 3, 3, 1};
     } else {
       DSM_REQUIRE(a->stride == 1, DSM_ERR_UNSUPPORTED);
@@ -1013,8 +1047,11 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   dsm_clear_stale_error();
   if (pl.kind == 3) {
-    dim3 grid(dsm_cdiv(a->Wo, NTHREADS), a->Ho, a->B * a->Do);
-    hipLaunchKernelGGL(deconv3d_cout1_kernel, grid, dim3(NTHREADS), 0, s, p);
+    p.ntx = dsm_cdiv(p.Wi, 32); p.nty = dsm_cdiv(p.Hi, 4);
+    const long nt = (long)p.B * p.Di * p.nty * p.ntx;
+    DSM_REQUIRE(nt < (1L << 31), DSM_ERR_UNSUPPORTED);
+    const size_t lds = (size_t)(2 * 5 * 33 * 8 + 27 * 8) * 16;     // 45.7 KB
+    hipLaunchKernelGGL(deconv3d_cout1_kernel, dim3((unsigned)nt), dim3(NTHREADS), lds, s, p);
     return dsm_launch_status();
   }
   if (pl.kind == 2) {
