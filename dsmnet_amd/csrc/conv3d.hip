@@ -667,12 +667,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
 // Same persistent pipeline as the MFMA kernels: the next (tile, chunk) is prefetched into
 // registers while the current chunk is reduced; CK = 8 keeps the LDS image at 32 KB so that
 // four workgroups share a CU and hide each other's barriers.
-// Known limit (stamps + PMC, profiles/): the kernel is bound by L1/TA line traffic, not by
-// FMAs or LDS -- every 8-channel chunk touches 32 B of each 128-B voxel line, and each input
-// slice is re-read for three output planes (~3.6 GB of line traffic for a 189 MB input).  The
-// fix is a z-sliding form (one slice staged once as whole voxels, three rotating
-// accumulators); a first attempt was defeated by register allocation (loop-invariant weight
-// reads hoisted / scalar file exhausted) and is left for a later round.
+// Known limit (stamps + PMC, profiles/r01_d_pmc.md): bound by L1/TA line traffic, not by FMAs
+// or LDS -- every 8-channel chunk touches 32 B of each 128-B voxel line and each input slice is
+// re-read for three output planes.  Cin = 32 (every head of the reference) therefore takes
+// conv3d_cout1_zslide_kernel below (83 us against 230 us at 48 x 96 x 320); this one remains
+// the general-Cin form.
 template <int CK>
 __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_kernel(ConvParams p,
                                                                    const float* __restrict__ w) {
@@ -760,6 +759,97 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_kernel(ConvParams p,
     DSM_STAMP(5);
     ck = nck; t = nt_;
     if (t >= end) break;
+  }
+}
+
+// Cout = 1, Cin = 32, z-sliding form (PSMNet classif heads at full size).  A workgroup owns an
+// 8 x 32 (y, x) column of `zseg` output planes and walks z: each input plane is staged ONCE as
+// whole 128-B voxels (full-line loads) and feeds three rotating accumulators -- plane p is the
+// dz = 0 / 1 / 2 tap plane of outputs p+1 / p / p-1.  Against the chunked kernel above this
+// divides the L1/TA line traffic by ~12 (4 channel chunks x 3 planes) and the LDS reads by 3.
+//  * LDS image [IY][IX] voxels at a pitch of 9 quads (144 B): the 16 lanes of a ds_read_b128
+//    group then fall on 16 distinct slots of the 256-B bank row; element e = tid + 256k lands
+//    at tid + (tid >> 3) + 288k, still an immediate offset.
+//  * weights [tap][32] through the scalar cache in 24 pinned phases per plane (9 x
+//    s_load_dwordx4 = 3 dz x 3 dx x 4 channels, then 3 LDS reads + 36 FMAs; 72 weights per
+//    phase spilled scalars).  The pointer is
+//    laundered per plane: the weight reads are loop-invariant, and hoisting 864 of them out of
+//    the plane loop is what exhausted the scalar file in the first attempt at this form.
+__global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_zslide_kernel(
+    ConvParams p, const float* __restrict__ w, int zseg) {
+  constexpr int TY = 8, IY = TY + 2, IX = 34, NQ = 8, PITCH = 9;
+  constexpr int NE = IY * IX * NQ;                       // 2720
+  constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;    // 11
+  extern __shared__ __attribute__((aligned(16))) f32x4 tile[];   // IY*IX*PITCH quads = 47.8 KB
+  typedef const float __attribute__((address_space(4))) cfloat;
+  typedef f32x4 __attribute__((address_space(4))) cquad;
+  const int tid = threadIdx.x;
+  const int r = tid & 31, ty = tid >> 5;
+  int id = blockIdx.x;
+  const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
+  const int ty0 = (id % p.nty) * TY; id /= p.nty;
+  const int nseg = (p.Do + zseg - 1) / zseg;
+  const int z0 = (id % nseg) * zseg, b = id / nseg;
+  const int z1 = min(z0 + zseg, p.Do);                   // output planes [z0, z1)
+
+  f32x4 pf[NPF];
+  unsigned goff[NPF];
+  stage_offsets<NPF, NE, NQ, IX, IY>(goff, tid, p.Hi, p.Wi, p.Cin);
+  const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(p.x, p.xbytes);
+  auto prefetch = [&](int pz) {
+    const StageBox box = stage_box(p.x, b, pz, ty0 - 1, tx0 - 1, p.Di, p.Hi, p.Wi, p.Cin, 0, 1, IY,
+                                   IX, true);
+    stage_prefetch<NPF, NE, NQ, IX, IY>(pf, goff, box, xrsrc, tid);
+  };
+  const int wbase = tid + (tid >> 3);                    // padded position of element `tid`
+  const f32x4* rd = tile + (ty * IX + r) * PITCH;        // this thread's voxel, tap (0, 0)
+  const int yo = ty0 + ty, xo = tx0 + r;
+  const bool live = yo < p.Ho && xo < p.Wo;
+  const float sc = p.scale ? p.scale[0] : 1.f, sh = p.shift ? p.shift[0] : 0.f;
+
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;                    // outputs pz-1, pz, pz+1
+  prefetch(max(z0 - 1, 0));
+  for (int pz = z0 - 1; pz <= z1; ++pz) {
+    if (pz >= 0 && pz < p.Di) {                          // planes outside the volume are zero
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NPF; ++k)
+        if ((k + 1) * NTHREADS <= NE || tid + k * NTHREADS < NE) tile[wbase + k * (NTHREADS / NQ) * PITCH] = pf[k];
+      __syncthreads();
+      if (pz + 1 <= z1 && pz + 1 < p.Di) prefetch(pz + 1);
+      cfloat* wc = (cfloat*)w;
+      asm volatile("" : "+s"(wc));                       // not loop-invariant as far as hipcc knows
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          f32x4 wv[3][3];                                // volatile: no merging across phases
+#pragma unroll
+          for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+              wv[dz][dx] = *(const volatile cquad*)(wc + ((dz * 3 + dy) * 3 + dx) * 32 + q * 4);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const f32x4 a = rd[(dy * IX + dx) * PITCH + q];
+            const f32x4 w0 = wv[0][dx], w1 = wv[1][dx], w2 = wv[2][dx];
+            a2 = fmaf(a.x, w0.x, a2); a2 = fmaf(a.y, w0.y, a2); a2 = fmaf(a.z, w0.z, a2); a2 = fmaf(a.w, w0.w, a2);
+            a1 = fmaf(a.x, w1.x, a1); a1 = fmaf(a.y, w1.y, a1); a1 = fmaf(a.z, w1.z, a1); a1 = fmaf(a.w, w1.w, a1);
+            a0 = fmaf(a.x, w2.x, a0); a0 = fmaf(a.y, w2.y, a0); a0 = fmaf(a.z, w2.z, a0); a0 = fmaf(a.w, w2.w, a0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int zo = pz - 1;                               // a0 has seen its three planes
+    if (zo >= z0 && zo < z1 && live) {
+      float v = a0 * sc + sh;
+      if (p.relu == 2) v = fmaxf(v, 0.f);
+      if (p.res) v += p.res[(((long)b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo];
+      if (p.relu == 1) v = fmaxf(v, 0.f);
+      p.y[(((long)b * p.Do + zo) * p.Ho + yo) * p.Wo + xo] = v;
+    }
+    a0 = a1; a1 = a2; a2 = 0.f;
   }
 }
 
@@ -947,7 +1037,7 @@ extern "C" int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Ci
 
 namespace {
 // One place decides the kernel variant; dsm_conv3d_fwd launches it, dsm_conv3d_plan names it.
-struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1
+struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1, 4 conv cout1 z-sliding
 
 int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   DSM_REQUIRE(a && a->x && a->w_packed && a->y, DSM_ERR_ARG);
@@ -978,7 +1068,9 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
       *pl = Plan{3, 2, 0, 0, 0, 3, 3, 1};
     } else {
       DSM_REQUIRE(a->stride == 1, DSM_ERR_UNSUPPORTED);
-      *pl = Plan{2, 1, 0, 0, 8, 3, 3, 1};
+      static int zslide = -1;                        // DSM_COUT1_ZSLIDE=0: chunked kernel (A/B runs)
+      if (zslide < 0) { const char* e = getenv("DSM_COUT1_ZSLIDE"); zslide = e ? atoi(e) : 1; }
+      *pl = Plan{(a->Cin == 32 && zslide) ? 4 : 2, 1, 0, 0, 8, 3, 3, 1};
     }
     return DSM_OK;
   }
@@ -1021,6 +1113,7 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
       break;
     case 1: snprintf(buf, len, "deconv3d_mfma_kernel<NT=%d,CK=%d>", pl.NT, pl.CK); break;
     case 2: snprintf(buf, len, "conv3d_cout1_kernel<CK=%d>", pl.CK); break;
+    case 4: snprintf(buf, len, "conv3d_cout1_zslide_kernel"); break;
     default: snprintf(buf, len, "deconv3d_cout1_kernel"); break;
   }
   return DSM_OK;
@@ -1052,6 +1145,20 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
     DSM_REQUIRE(nt < (1L << 31), DSM_ERR_UNSUPPORTED);
     const size_t lds = (size_t)(2 * 5 * 33 * 8 + 27 * 8) * 16;     // 45.7 KB
     hipLaunchKernelGGL(deconv3d_cout1_kernel, dim3((unsigned)nt), dim3(NTHREADS), lds, s, p);
+    return dsm_launch_status();
+  }
+  if (pl.kind == 4) {
+    p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, 8);
+    // z-segment: the longest of 16/8/4/2 planes that still gives the 768 workgroup slots
+    // (3 per CU) most of a round; each segment stages two halo planes on top of its own
+    const long cols = (long)p.B * p.nty * p.ntx;
+    int zseg = 16;
+    while (zseg > 2 && cols * dsm_cdiv(p.Do, zseg) < 600) zseg >>= 1;
+    const long nt = cols * dsm_cdiv(p.Do, zseg);
+    DSM_REQUIRE(nt < (1L << 31), DSM_ERR_UNSUPPORTED);
+    const size_t lds = (size_t)10 * 34 * 9 * 16;                   // 47.8 KB
+    hipLaunchKernelGGL(conv3d_cout1_zslide_kernel, dim3((unsigned)nt), dim3(NTHREADS), lds, s, p,
+                       p.w, zseg);
     return dsm_launch_status();
   }
   if (pl.kind == 2) {

@@ -97,6 +97,14 @@ def test_conv3d_large_tiles(cv):
     run_case(cv, 64, 64, 2, True, (1, 12, 32, 64), with_res=True)
 
 
+def test_conv3d_cout1_zslide_segments(cv):
+    """Classifier head 32->1 at sizes where the z-sliding kernel walks 8- and 16-plane segments
+    (ragged last segment, ragged rows/columns, cropped skip as in PSMNet's cost2/cost3)."""
+    run_case(cv, 32, 1, 1, False, (1, 40, 96, 320), with_bn=False, with_res=True, relu=False)
+    run_case(cv, 32, 1, 1, False, (1, 37, 93, 317), with_bn=False, relu=False)
+    run_case(cv, 32, 1, 1, False, (1, 33, 190, 610), with_bn=False, with_res=True, relu=False)
+
+
 def test_relayout_roundtrip(cv):
     x = seeded(3, 2, 24, 5, 7, 9).cuda()
     cl = cv.to_channels_last_3d(x)
