@@ -47,6 +47,10 @@ SIGNATURES = {
     "dsm_conv3d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     "dsm_conv3d_cout1_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "dsm_volume_relayout": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
+    "dsm_spp_branch_floats": (ctypes.c_size_t, [c_int] * 3),
+    "dsm_spp_pool8": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
+    "dsm_spp_branches": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
+    "dsm_spp_concat": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
 }
 
 _lib = None
@@ -84,7 +88,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.dsm_abi_version() != 2:
+    if lib.dsm_abi_version() != 3:
         raise DsmnetHipError("libdsmnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -405,6 +405,44 @@ def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     return y
 
 
+def spp_head(raw, skip, w_t, scale, shift):
+    """PSMNet's SPP head in three launches (csrc/spp.hip; models/psmnet/submodule.py:81-99,
+    126-137): ``raw`` (B,64,H,W) and ``skip`` (B,128,H,W) channels_last -> the 320-channel
+    concat [raw | skip | branch4 | branch3 | branch2 | branch1] (B,320,H,W) channels_last.
+    ``w_t`` (4,128,32): the branch4..branch1 1x1 weights, input-channel major; ``scale`` /
+    ``shift`` (4,32): their folded BN.  Inference only."""
+    _require_device("spp_head", raw, skip, w_t, scale, shift)
+    B, cr, H, W = raw.shape
+    if cr != 64 or tuple(skip.shape) != (B, 128, H, W):
+        raise ValueError("spp_head: expected raw (B,64,H,W) and skip (B,128,H,W), got %s and %s"
+                         % (tuple(raw.shape), tuple(skip.shape)))
+    if tuple(w_t.shape) != (4, 128, 32) or tuple(scale.shape) != (4, 32) or tuple(shift.shape) != (4, 32):
+        raise ValueError("spp_head: w_t (4,128,32), scale/shift (4,32) expected")
+    if H < 64 or W < 64:
+        raise ValueError("spp_head: the 64x64 pooling branch needs H, W >= 64 at 1/4 resolution "
+                         "(got %dx%d)" % (H, W))
+    raw = raw.contiguous(memory_format=_CL2D)
+    skip = skip.contiguous(memory_format=_CL2D)
+    w_t, scale, shift = w_t.contiguous(), scale.contiguous(), shift.contiguous()
+    lib = _lib.load()
+    h8, w8 = H // 8, W // 8
+    p8 = torch.empty((B, h8, w8, 128), device=raw.device, dtype=torch.float32)
+    br = torch.empty(lib.dsm_spp_branch_floats(B, h8, w8), device=raw.device, dtype=torch.float32)
+    out = torch.empty((B, 320, H, W), device=raw.device, dtype=torch.float32, memory_format=_CL2D)
+    with torch.cuda.device(raw.device):
+        with _timed("spp_pool8_kernel", 4.0 * (skip.numel() + p8.numel())):
+            rc = lib.dsm_spp_pool8(_p(skip), _p(p8), B, H, W, _stream())
+        _lib.check(rc, "dsm_spp_pool8")
+        with _timed("spp_branches_kernel", 4.0 * (p8.numel() + br.numel())):
+            rc = lib.dsm_spp_branches(_p(p8), _p(w_t), _p(scale), _p(shift), _p(br), B, h8, w8,
+                                      _stream())
+        _lib.check(rc, "dsm_spp_branches")
+        with _timed("spp_concat_kernel", 4.0 * (raw.numel() + skip.numel() + out.numel())):
+            rc = lib.dsm_spp_concat(_p(raw), _p(skip), _p(br), _p(out), B, H, W, _stream())
+        _lib.check(rc, "dsm_spp_concat")
+    return out
+
+
 # ----------------------------------------------------------------------------
 # Conv3d / ConvTranspose3d (k=3) with autograd: training through the 3-D trunk
 # ----------------------------------------------------------------------------

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from ... import costvolume as cv
 from ...blocks2d import ConvBN2d, _Folded2d, run_conv2d, stage_image_nhwc16
-from ...blocks3d import ConvBN3d
+from ...blocks3d import ConvBN3d, _versions
 
 
 def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
@@ -64,7 +64,9 @@ class disparityregression(nn.Module):
 
 
 class feature_extraction(nn.Module):
-    """2-D SPP tower, (B,3,H,W) -> (B,32,H/4,W/4).  Stock torch layers (MIOpen)."""
+    """2-D SPP tower, (B,3,H,W) -> (B,32,H/4,W/4).  Eval mode on the GPU: every convolution on
+    the MFMA kernel (blocks2d) and the SPP head in three launches (csrc/spp.hip); training and
+    CPU tensors take the stock torch layers."""
 
     def __init__(self):
         super(feature_extraction, self).__init__()
@@ -97,14 +99,8 @@ class feature_extraction(nn.Module):
         layers += [block(self.inplanes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
-    def forward(self, x):
-        if x.is_cuda and not self.training and not torch.is_grad_enabled():
-            x = stage_image_nhwc16(x)                      # NHWC, 3 -> 16 staged channels
-        for i in (0, 2, 4):
-            x = self.firstconv[i](x, relu=True)
-        x = self.layer1(x)
-        raw = self.layer2(x)
-        skip = self.layer4(self.layer3(raw))
+    def _spp_stock(self, raw, skip):
+        """The reference's SPP head with stock torch ops (training, autograd, CPU)."""
         size = skip.shape[2:]
         # SPP pooling as a cascade: AvgPool(8), then 2x2 averages give AvgPool(16/32/64)
         # exactly (equal windows that tile, floor semantics preserved) -- the direct 64x64
@@ -115,7 +111,38 @@ class feature_extraction(nn.Module):
             branch = getattr(self, "branch%d" % i)
             y = branch[1](pooled, relu=True)          # convbn + ReLU ([0] is the AvgPool2d)
             pyramid.append(F.interpolate(y, size=size, mode="bilinear", align_corners=False))
-        x = torch.cat([raw, skip] + pyramid, dim=1)
+        return torch.cat([raw, skip] + pyramid, dim=1)
+
+    def _spp_params(self):
+        """(w_t (4,128,32), scale (4,32), shift (4,32)) of branch4..branch1 with BN folded,
+        cached until a parameter or running statistic changes."""
+        convs = [getattr(self, "branch%d" % i)[1] for i in (4, 3, 2, 1)]
+        srcs = [t for c in convs for t in (c[0].weight, c[1].weight, c[1].bias,
+                                           c[1].running_mean, c[1].running_var)]
+        key = _versions(*srcs)
+        if getattr(self, "_spp_key", None) != key:
+            with torch.no_grad():
+                w_t = torch.stack([c[0].weight.reshape(32, 128).t() for c in convs]).contiguous()
+                inv = [torch.rsqrt(c[1].running_var + c[1].eps) for c in convs]
+                scale = torch.stack([c[1].weight * i for c, i in zip(convs, inv)])
+                shift = torch.stack([c[1].bias - c[1].running_mean * s
+                                     for c, s in zip(convs, scale)])
+            self._spp_cache = (w_t, scale.contiguous(), shift.contiguous())
+            self._spp_key = key
+        return self._spp_cache
+
+    def forward(self, x):
+        if x.is_cuda and not self.training and not torch.is_grad_enabled():
+            x = stage_image_nhwc16(x)                      # NHWC, 3 -> 16 staged channels
+        for i in (0, 2, 4):
+            x = self.firstconv[i](x, relu=True)
+        x = self.layer1(x)
+        raw = self.layer2(x)
+        skip = self.layer4(self.layer3(raw))
+        if skip.is_cuda and not self.training and not torch.is_grad_enabled():
+            x = cv.spp_head(raw, skip, *self._spp_params())       # three launches (csrc/spp.hip)
+        else:
+            x = self._spp_stock(raw, skip)
         x = self.lastconv[0](x, relu=True)
         if not hasattr(self, "_last_fold"):
             self._last_fold = _Folded2d()

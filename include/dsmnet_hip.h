@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DSM_ABI_VERSION 2
+#define DSM_ABI_VERSION 3
 
 #define DSM_OK               0
 #define DSM_ERR_ARG         -1   /* null pointer, non-positive size, bad enum      */
@@ -192,6 +192,23 @@ int dsm_conv3d_cout1_bwd(const void* x, const void* g, const void* w_packed, voi
  * torch modules that want contiguous NCDHW). to_ndhwc = 1: src NCDHW. */
 int dsm_volume_relayout(const void* src, void* dst, int B, int C, int D, int H, int W,
                         int to_ndhwc, dsm_stream_t stream);
+
+/* PSMNet spatial-pyramid-pooling head on NHWC fp32 maps -- replaces, in eval mode,
+ * models/psmnet/submodule.py:81-99 (branch1..4: AvgPool2d(64/32/16/8) -> convbn(128,32,1,1,0,1)
+ * -> ReLU; convbn pads the 1x1 convolution by 1, :10-13) and :126-137 (bilinear upsample to the
+ * 1/4-resolution grid + concat [raw 64 | skip 128 | branch4 | branch3 | branch2 | branch1]).
+ *   dsm_spp_pool8     skip (B,H,W,128) -> p8 (B,H/8,W/8,128), 8x8 means (floor)
+ *   dsm_spp_branches  p8 -> four maps, back to back in `branches` (dsm_spp_branch_floats floats):
+ *                     map i (i = 0..3 = branch4..branch1) is (B, h8/2^i + 2, w8/2^i + 2, 32);
+ *                     w_t [4][128][32] (input-channel major), scale/shift [4][32] = folded BN
+ *   dsm_spp_concat    raw (B,H,W,64), skip (B,H,W,128), branches -> out (B,H,W,320)
+ * H, W >= 64 (the reference's 64x64 pool needs a full window). */
+size_t dsm_spp_branch_floats(int B, int h8, int w8);
+int dsm_spp_pool8(const void* skip, void* p8, int B, int H, int W, dsm_stream_t stream);
+int dsm_spp_branches(const void* p8, const void* w_t, const void* scale, const void* shift,
+                     void* branches, int B, int h8, int w8, dsm_stream_t stream);
+int dsm_spp_concat(const void* raw, const void* skip, const void* branches, void* out,
+                   int B, int H, int W, dsm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -119,6 +119,20 @@ def _up2(x):
 # =============================================================================
 # PSMNet (stacked hourglass)
 # =============================================================================
+def psmnet_spp(n, raw, skip, p="feature_extraction"):
+    """SPP head of ``feature_extraction`` -- models/psmnet/submodule.py:81-99 (branches) and
+    :126-137 (upsample + concat).  The 1x1 branch convolutions run with padding 1 (``convbn``
+    pads by its dilation, ``:10-13``)."""
+    size = tuple(skip.shape[2:])
+    branches = []
+    for idx, pool in ((1, 64), (2, 32), (3, 16), (4, 8)):
+        b = F.avg_pool2d(skip, pool, stride=pool)
+        key = "%s.branch%d.1" % (p, idx)
+        b = F.relu(n.bn(n.conv(b, key + ".0", 32, 1, 1, pad=1, dil=1), key + ".1"))
+        branches.append(F.interpolate(b, size=size, mode="bilinear", align_corners=False))
+    return torch.cat([raw, skip, branches[3], branches[2], branches[1], branches[0]], dim=1)
+
+
 def psmnet_features(n, x, p="feature_extraction"):
     """``feature_extraction`` -- models/psmnet/submodule.py:65-140.
 
@@ -147,13 +161,7 @@ def psmnet_features(n, x, p="feature_extraction"):
     raw = layer(x, "layer2", 64, 16, 2, 1)
     x = layer(raw, "layer3", 128, 3, 1, 1)
     skip = layer(x, "layer4", 128, 3, 1, 2)
-    size = tuple(skip.shape[2:])
-    branches = []
-    for idx, pool in ((1, 64), (2, 32), (3, 16), (4, 8)):
-        b = F.avg_pool2d(skip, pool, stride=pool)
-        b = F.relu(cbn(b, "%s.branch%d.1" % (p, idx), 32, 1, 1, 1))
-        branches.append(F.interpolate(b, size=size, mode="bilinear", align_corners=False))
-    x = torch.cat([raw, skip, branches[3], branches[2], branches[1], branches[0]], dim=1)
+    x = psmnet_spp(n, raw, skip, p)
     x = F.relu(cbn(x, p + ".lastconv.0", 128, 3, 1, 1))
     return n.conv(x, p + ".lastconv.2", 32, 1, 1, pad=0)
 

@@ -1,0 +1,56 @@
+"""Timing of a PSMNet training step (BASELINE config #5 in fp32, one MI355X): train-mode forward,
+smooth-L1 on the three heads, backward, SGD step.  Prints ms/step and the per-kernel breakdown
+of the HIP launches (forward, bwd-data and bwd-weight kernels)."""
+import sys
+sys.path.insert(0, ".")
+import torch
+import torch.nn.functional as F
+from dsmnet_amd import costvolume as cv
+from dsmnet_amd.models import model_create_by_name
+
+H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (256, 512)
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+torch.manual_seed(0)
+m = model_create_by_name("psmnet", 192).cuda().train()
+for i in (1, 2, 3):
+    getattr(m, "classif%d" % i)[2].weight.data.mul_(1e-3)
+left = torch.rand(B, 3, H, W, device="cuda")
+right = torch.roll(left, -6, dims=3)
+target = torch.full((B, H, W), 6.0, device="cuda")
+opt = torch.optim.SGD(m.parameters(), lr=1e-4)
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    _, preds = m(left, right)
+    loss = sum(w * F.smooth_l1_loss(p, target) for w, p in zip((0.5, 0.7, 1.0), preds))
+    loss.backward()
+    opt.step()
+    return loss
+
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+timer = cv.LaunchTimer()
+cv.set_timer(timer)
+N = 5
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(N):
+    loss = step()
+b.record()
+torch.cuda.synchronize()
+cv.set_timer(None)
+ms = a.elapsed_time(b) / N
+print("PSMNet training step %dx%d batch %d D=192 fp32: %.1f ms/step (%.2f pairs/s), loss %.4f"
+      % (H, W, B, ms, B * 1e3 / ms, loss.item()))
+tot = 0.0
+for k, v in sorted(timer.summary().items(), key=lambda kv: -kv[1]["ms"]):
+    n = v["launches"]
+    tot += v["ms"] / N
+    rate = v["work"] / (v["ms"] * 1e-3)
+    print("   %-48s x%-4d %8.1f us avg %8.2f ms/step %8.2f %s" % (
+        k, n // N, v["ms"] / n * 1e3, v["ms"] / N, rate / 1e12, "TFLOP/s" if ("mfma" in k or "wgrad" in k) else "TB/s"))
+print("   HIP kernels %.1f ms/step, everything else (stock torch: towers, BN, ReLU, adds, optimizer) %.1f ms/step"
+      % (tot, ms - tot))
