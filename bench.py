@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="time eager launches instead of hipGraph replays")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the second, instrumented pass (per-launch HIP events -> rooflines)")
     args = ap.parse_args()
@@ -163,11 +165,24 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             preds = model(left, right)[1]
+        # One step = one whole forward.  By default its ~110 launches are replayed from a
+        # hipGraph captured once (same kernels, same work; the host launch path leaves the
+        # critical path, which keeps 8 ranks on one host from competing for cores).
+        step, launch = (lambda: model(left, right)[1]), "eager launches"
+        if not args.no_graph:
+            try:
+                from dsmnet_amd.graphs import GraphedForward
+                graphed = GraphedForward(model, left, right)
+                step, launch = (lambda: graphed.replay()[1]), "hipGraph replay of the whole forward"
+            except Exception as e:                       # capture refused: time eager launches
+                print("bench.py: hipGraph capture failed (%s); timing eager launches" % e,
+                      file=sys.stderr)
+        preds = step()
         # the timed region: K steps, nothing but the forward passes between the barriers
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            preds = model(left, right)[1]
+            preds = step()
         barrier()
         elapsed = time.perf_counter() - t0
         # the same K steps again with two HIP events around every launch of this library (on
@@ -201,7 +216,8 @@ def main():
                                    "per GPU per step (BASELINE configs[3]: batch 8 over 8 GPUs)",
                        "height": H, "width": W, "maxdisp": MAXDISP, "pairs_per_gpu_per_step": 1,
                        "heads": 3, "parallelism": "pairs sharded over ranks, no collective",
-                       "weights": "reference init (seed 0), BN + heads calibrated"},
+                       "weights": "reference init (seed 0), BN + heads calibrated",
+                       "launch": launch},
         }
         if timer is not None:
             roofs = kernel_rooflines(timer.summary(), args.steps)
@@ -213,8 +229,8 @@ def main():
             # stock torch ops, launch gaps and the event records themselves, in the instrumented pass
             result["other_ms_per_step"] = round(instrumented / args.steps * 1e3 - hip_ms, 3)
             result["kernel_timing"] = {
-                "how": "the same %d steps run again right after the timed region with two HIP "
-                       "events per launch on the launch stream" % args.steps,
+                "how": "%d eager steps right after the timed region with two HIP events per "
+                       "launch on the launch stream" % args.steps,
                 "instrumented_ms_per_step": round(instrumented / args.steps * 1e3, 3)}
         if world == 1 and not args.no_cpu_baseline:
             base, err = cpu_baseline(model, left, right, preds)

@@ -161,3 +161,29 @@ def test_psmnet_batch_of_two(hip_lib, golden_e2e):
         assert pb.shape == (2, 256, 512)
         assert maxerr(pb[1:], po) <= 1e-4
     golden_e2e.compare("e2e.psmnet.pred3", both[0][:1], DISP_TOL)
+
+
+def test_graphed_forward_equals_eager(hip_lib):
+    """hipGraph replay of the whole PSMNet forward (dsmnet_amd/graphs.py): bit-identical to eager
+    launches, and new inputs of the captured shape are picked up."""
+    from dsmnet_amd.graphs import GraphedForward
+    from dsmnet_amd.models import model_create_by_name
+    torch.manual_seed(0)
+    m = model_create_by_name("psmnet", 192).cuda().eval()
+    for i in (1, 2, 3):
+        getattr(m, "classif%d" % i)[2].weight.data.mul_(1e-3)
+    a, b = torch.rand(1, 3, 256, 512, device="cuda"), torch.rand(1, 3, 256, 512, device="cuda")
+    c, d = torch.rand(1, 3, 256, 512, device="cuda"), torch.rand(1, 3, 256, 512, device="cuda")
+    g = GraphedForward(m, a, b)
+    with torch.no_grad():
+        want_ab = [t.clone() for t in m(a, b)[1]]
+        want_cd = [t.clone() for t in m(c, d)[1]]
+    got_cd = [t.clone() for t in g(c, d)[1]]
+    got_ab = [t.clone() for t in g(a, b)[1]]
+    for w, x in zip(want_ab + want_cd, got_ab + got_cd):
+        assert torch.equal(w, x)
+    assert not torch.equal(got_ab[2], got_cd[2])
+    with pytest.raises(ValueError):
+        g(a[:, :, :128], b[:, :, :128])
+    with pytest.raises(ValueError):
+        GraphedForward(m.train(), a, b)
