@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_summary.md from a rocprofv3 --kernel-trace --stats run of bench.py and the
+un-profiled bench line.  usage: profile_summary.py <tag> <kernel_stats.csv> <bench.json> <bench_under_rocprof.json>"""
+import csv
+import json
+import re
+import sys
+
+tag, stats_csv, bench_json, prof_json = sys.argv[1:5]
+bench = json.load(open(bench_json))
+prof = json.load(open(prof_json))
+rows = list(csv.DictReader(open(stats_csv)))
+OURS = ("conv3d_mfma", "deconv3d", "cout1", "soft_argmin", "volume_", "pack_weights", "spp_", "corr1d")
+
+
+def short(n):
+    n = re.sub(r"^void\s+", "", n).replace("(anonymous namespace)::", "")
+    return re.sub(r"\(.*$", "", n)[:80]
+
+
+def plan_name(n):
+    """rocprof's demangled template name -> the name bench.py uses"""
+    m = re.match(r"conv3d_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", n)
+    if m:
+        S, NT, TM, CK, KZ, K, DIL = map(int, m.groups())
+        return ("conv3d_mfma_kernel<S=%d,NT=%d,TM=%d,CK=%d>" % (S, NT, TM, CK) if KZ == 3 else
+                "conv2d_mfma_kernel<S=%d,NT=%d,TM=%d,K=%d,DIL=%d>" % (S, NT, TM, K, DIL))
+    m = re.match(r"deconv3d_mfma_kernel<(\d+), (\d+)>", n)
+    if m:
+        return "deconv3d_mfma_kernel<NT=%s,CK=%s>" % m.groups()
+    n = re.sub(r"<.*$", "", n)
+    return {"soft_argmin_up4_kernel": "soft_argmin_fwd_kernel"}.get(n, n)
+
+
+total = sum(float(r["TotalDurationNs"]) for r in rows)
+ours = [r for r in rows if any(k in r["Name"] for k in OURS)]
+ours_total = sum(float(r["TotalDurationNs"]) for r in ours)
+roofs = bench.get("rooflines", {})
+print("# Round 1, run %s — `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline`\n" % tag.upper())
+print("PSMNet D=192, 384x1280, 1 MI355X.  Un-profiled bench line (`%s_bench.json`): **%.1f pairs/s**, %.2f ms/step (%s);"
+      % (tag, bench["value"], bench["ms_per_step"], bench["config"].get("launch", "eager launches")))
+cb = bench.get("cpu_baseline")
+if cb:
+    print("CPU baseline %.3f pairs/s on %d host threads; parity vs CPU oracle %.1e px." % (cb["value"], cb["cores"], bench["parity_max_abs_px_vs_cpu"]))
+print("Same command under the profiler: %.1f pairs/s.\n" % prof["value"])
+print("Kernels of this repository are %.1f %% of all GPU time in the trace (the rest: MIOpen/torch kernels of the BN + head calibration passes, image staging, layout copies).\n" % (100 * ours_total / total))
+print("| kernel (this repo) | calls | avg us (rocprof) | avg us (bench HIP events) |")
+print("|---|---|---|---|")
+for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"])):
+    s = short(r["Name"])
+    ev = roofs.get(plan_name(s), {}).get("avg_launch_us")
+    print("| `%s` | %s | %.1f | %s |" % (s, r["Calls"], float(r["AverageNs"]) / 1e3, "%.1f" % ev if ev else "-"))
+d = bench["roofline"]
+print("\nDominant kernel `%s`: %.1f %s = %.1f %% of the %.1f peak (%d launches/step, %.2f ms/step)."
+      % (d["kernel"], d["achieved"], d["unit"], 100 * d["frac"], d["peak"], d["launches_per_step"], d["ms_per_step"]))
+v = roofs.get("volume_ndhwc_fwd_kernel")
+if v:
+    print("Cost-volume build: %.1f us by in-bench events -> %.0f GB/s = %.1f %% of 8 TB/s (north-star target >= 60 %%), %.1f %% of the 6.29 TB/s copy ceiling; PMC traffic %.1f MB vs %.1f MB algorithmic (profiles/r01_d_pmc.md)."
+          % (v["avg_launch_us"], v["achieved"], 100 * v["frac"], 100 * v.get("frac_of_copy_ceiling", 0), (v.get("traffic") or 0) / 1e6, v["work_per_launch"] / 1e6))
