@@ -70,7 +70,8 @@ def allreduce_gradients(parameters, world=None):
     """Average gradients across ranks with ONE flat all-reduce (sum, then / world).
     Parameters without a gradient contribute zeros so that every rank reduces the same
     buffer.  Returns the number of elements reduced."""
-    world = dist.get_world_size() if world is None else world
+    if world is None:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     params = [p for p in parameters if p.requires_grad]
     if world == 1 or not params:
         return 0

@@ -32,6 +32,9 @@ class Golden(object):
         self.z = np.load(os.path.join(GOLDEN, "golden_%s.npz" % part), allow_pickle=False)
         self.meta = json.loads(bytes(self.z["meta"]).decode())
 
+    def __getitem__(self, name):
+        return self.z[name]
+
     def has(self, name):
         return (name + ".sample") in self.z
 
@@ -70,6 +73,11 @@ def golden_blocks():
 @pytest.fixture(scope="session")
 def golden_e2e():
     return Golden("e2e")
+
+
+@pytest.fixture(scope="session")
+def golden_train():
+    return Golden("train")
 
 
 @pytest.fixture(scope="session")

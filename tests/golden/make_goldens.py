@@ -381,14 +381,97 @@ def gen_e2e(store):
                    "psmnet": {"seed": 0, "image_seed": 63, "hw": [256, 512]}}
 
 
+
+# ----------------------------------------------------------------------------
+# G6: supervised objective and bookkeeping
+# ----------------------------------------------------------------------------
+def gen_train(store):
+    """losses/loss.py does not parse under Python 3 (``print`` statements at :320-321) and
+    imports SSIM/cv2-era modules, so the lines of the supervised path are executed from the
+    file text as methods of a holder class -- the same approach as the inline volume builds."""
+    from oracle import train as OT
+    print("G6 supervised loss (losses/loss.py:36-44,326-338,379-392,407-422; stereo.py:95-113)")
+    body = "".join("    " + l + "\n" for part in (
+        ref_lines("losses/loss.py", 36, 44), ref_lines("losses/loss.py", 326, 338),
+        ref_lines("losses/loss.py", 379, 392), ref_lines("losses/loss.py", 407, 422),
+        ref_lines("stereo.py", 95, 101), ref_lines("stereo.py", 103, 113))
+        for l in part.splitlines())
+    ns = {"torch": torch, "F": F}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exec("class Ref(object):\n" + body, ns)
+    ref = ns["Ref"]()
+    ref.lossfun = ref.loss_supervised
+
+    cases = []
+    for seed, shape, frac_valid, smooth in ((1, (2, 1, 24, 40), 0.7, True), (2, (1, 1, 17, 33), 1.0, False),
+                                           (3, (1, 1, 8, 8), 0.0, True), (4, (3, 1, 16, 16), 0.3, True)):
+        gt = seeded(seed, *shape).abs() * 40
+        keep = torch.rand(shape, generator=torch.Generator().manual_seed(seed + 50)) < frac_valid
+        gt = gt * keep
+        pred = gt + seeded(seed + 100, *shape) * 3
+        want = ref.loss_supervised(gt, pred, smooth, 1.0)
+        mine = OT.loss_supervised(gt, pred, smooth, 1.0)
+        if isinstance(want, int):
+            assert want == 0 and mine == 0
+            want = torch.zeros(())
+        else:
+            check("loss_supervised seed %d" % seed, want.double(), torch.as_tensor(mine), 1e-6)
+        tag = "train.loss.%d" % seed
+        store[tag] = np.float64(float(want))
+        cases.append({"seed": seed, "shape": list(shape), "frac_valid": frac_valid, "smooth": smooth})
+        d1, epe = ref.accuracy(pred, gt) if frac_valid > 0 else (torch.zeros(()), torch.zeros(()))
+        if frac_valid > 0:
+            od1, oepe = OT.accuracy(pred.numpy(), gt.numpy())
+            check("accuracy D1 seed %d" % seed, torch.as_tensor(float(d1)), torch.as_tensor(float(od1)), 1e-6)
+            check("accuracy EPE seed %d" % seed, torch.as_tensor(float(epe)), torch.as_tensor(float(oepe)), 1e-6)
+        store["train.d1.%d" % seed] = np.float64(float(d1))
+        store["train.epe.%d" % seed] = np.float64(float(epe))
+    META["train_cases"] = cases
+
+    # pyramid of 7 outputs (DispNetC / iResNet: scale_disps 0..6) under three schedules
+    gt = seeded(7, 1, 1, 64, 128).abs() * 30
+    disps = [seeded(70 + l, 1, 1, -(-64 // 2 ** l), -(-128 // 2 ** l)) * 2 + 20 for l in range(7)]
+    scales = list(range(7))
+    sched = []
+    for epoch, maxepoch in ((0, 37), (10, 37), (36, 37), (37, 37), (5, 0)):
+        ref.count_levels, ref.maxepoch_weight_adjust = 7, maxepoch
+        ref.Weight_Adjust_levels(epoch)
+        ow = OT.weight_adjust_levels(7, maxepoch, epoch)
+        assert np.allclose(ref.weight_levels, ow, atol=1e-12), (ref.weight_levels, ow)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = ref.losses_pyramid0(gt, disps, scales, True)
+        mine = OT.losses_pyramid0(ow, gt, disps, scales, True)
+        check("losses_pyramid0 epoch %d/%d" % (epoch, maxepoch), want.double(), torch.as_tensor(mine), 1e-6)
+        store["train.weights.%d_%d" % (epoch, maxepoch)] = np.asarray(ref.weight_levels, dtype=np.float64)
+        store["train.pyramid.%d_%d" % (epoch, maxepoch)] = np.float64(float(want))
+        sched.append([epoch, maxepoch])
+    META["train_pyramid"] = {"gt_seed": 7, "disp_seed0": 70, "h": 64, "w": 128, "schedules": sched}
+
+    class _Opt(object):
+        def __init__(self):
+            self.param_groups = [{"lr": -1.0}]
+    lrs = []
+    for epoch in (0, 49, 50, 69, 70, 131):
+        o = _Opt()
+        ref.lr_adjust(o, 50, 20, 1e-4, epoch)
+        got = o.param_groups[0]["lr"]
+        mine = OT.lr_adjust(1e-4, 50, 20, epoch)
+        assert (got == -1.0 and mine is None) or abs(got - mine) < 1e-18, (epoch, got, mine)
+        lrs.append(got)
+    store["train.lr"] = np.asarray(lrs, dtype=np.float64)
+    print("  lr schedule, weight schedule: oracle == reference")
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["ops", "blocks", "e2e"], default=None)
+    ap.add_argument("--only", choices=["ops", "blocks", "e2e", "train"], default=None)
     args = ap.parse_args()
     if not RL.available():
         raise SystemExit("needs the reference tree at %s (build container only)" % RL.REFERENCE_ROOT)
     torch.set_num_threads(os.cpu_count() or 1)
-    for part, fn in (("ops", gen_ops), ("blocks", gen_blocks), ("e2e", gen_e2e)):
+    for part, fn in (("ops", gen_ops), ("blocks", gen_blocks), ("e2e", gen_e2e), ("train", gen_train)):
         if args.only and args.only != part:
             continue
         store = {}

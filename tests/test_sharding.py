@@ -67,3 +67,67 @@ def test_world_size_2_gloo():
         assert p.exitcode == 0
     assert sorted(r[0] for r in results) == [0, 1]
     assert all(r[1] and r[2] for r in results), results
+
+
+class _ToyStereo(torch.nn.Module):
+    """A stock-torch stand-in with the models' call contract: (imL, imR) -> (scales, disps)."""
+
+    def __init__(self):
+        super(_ToyStereo, self).__init__()
+        self.count_levels = 2
+        self.conv = torch.nn.Conv2d(6, 1, 3, padding=1)
+
+    def forward(self, imL, imR, mode="train"):
+        d0 = self.conv(torch.cat([imL, imR], 1))
+        return [0, 1], [d0, torch.nn.functional.avg_pool2d(d0, 2)]
+
+
+def _batch(seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.cat([torch.rand(2, 6, 8, 12, generator=g), torch.rand(2, 1, 8, 12, generator=g) * 9 + 1], 1)
+
+
+def _train_worker(rank, world, port, q):
+    from dsmnet_amd import train
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sharding.init_from_env("gloo")
+    torch.manual_seed(0)
+    model = _ToyStereo()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    lossfun = train.losses("supervised", 2, 4)
+    lossfun.Weight_Adjust_levels(1)
+    train.train_step(model, opt, lossfun, _batch(100 + rank))        # world from the process group
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, [p.detach().numpy().copy() for p in model.parameters()]))   # by value
+
+
+def test_train_step_world_size_2_equals_averaged_gradients():
+    from dsmnet_amd import train
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process: the mean of the two ranks' gradients, one SGD step
+    torch.manual_seed(0)
+    model = _ToyStereo()
+    lossfun = train.losses("supervised", 2, 4)
+    lossfun.Weight_Adjust_levels(1)
+    grads = []
+    for r in range(2):
+        model.zero_grad()
+        b = _batch(100 + r)
+        s, d = model(b[:, :3], b[:, 3:6])
+        lossfun({"disp_gt": b[:, 6:7], "disps": d, "scale_disps": s, "flag_smooth": True}).backward()
+        grads.append([p.grad.clone() for p in model.parameters()])
+    want = [p.detach() - 0.1 * (g0 + g1) / 2 for p, g0, g1 in zip(model.parameters(), *grads)]
+    for r in (0, 1):
+        for got, w in zip(results[r], want):
+            assert torch.allclose(torch.from_numpy(got), w, atol=1e-6)
