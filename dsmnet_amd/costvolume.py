@@ -405,6 +405,32 @@ def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     return y
 
 
+def warp_abs_error(left, right, disp, delt):
+    """``|left - imwrap_BCHW(right, disp)|`` in one pass (csrc/warp.hip; utils/imwrap.py:37-72,
+    models/iresnet.py:169-170).  ``left=None``: the warped map itself.  ``delt`` is the
+    reference's random epsilon (a Python float drawn by the caller).  NCHW fp32; inference only."""
+    _require_device("warp_abs_error", right, disp, left)
+    B, C, H0, W0 = right.shape
+    if disp.dim() != 4 or disp.shape[0] != B or disp.shape[1] != 1:
+        raise ValueError("warp_abs_error: disp must be (B,1,H,W), got %s" % (tuple(disp.shape),))
+    H, W = disp.shape[2:]
+    if min(H, W, H0, W0) <= 1:
+        raise ValueError("warp_abs_error: maps must be larger than 1x1")        # imwrap.py:48
+    if left is not None and tuple(left.shape) != (B, C, H, W):
+        raise ValueError("warp_abs_error: left %s does not match (B,C)=%s and disp %s"
+                         % (tuple(left.shape), (B, C), (H, W)))
+    right, disp = right.contiguous(), disp.contiguous()
+    left = None if left is None else left.contiguous()
+    out = torch.empty((B, C, H, W), device=right.device, dtype=torch.float32)
+    n = out.numel()
+    with torch.cuda.device(right.device), _timed("warp_abs_error_kernel",
+                                                 4.0 * (right.numel() + disp.numel() + n * (2 if left is not None else 1))):
+        rc = _lib.load().dsm_warp_abs_error(None if left is None else _p(left), _p(right), _p(disp),
+                                            _p(out), B, C, H, W, H0, W0, float(delt), _stream())
+    _lib.check(rc, "dsm_warp_abs_error")
+    return out
+
+
 def spp_head(raw, skip, w_t, scale, shift):
     """PSMNet's SPP head in three launches (csrc/spp.hip; models/psmnet/submodule.py:81-99,
     126-137): ``raw`` (B,64,H,W) and ``skip`` (B,128,H,W) channels_last -> the 320-channel

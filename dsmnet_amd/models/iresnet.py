@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import costvolume as cv
 from .util_conv import Corr1d, conv2d_bn, deconv2d_bn, net_init
 from .util_fun import myCat2d
 
@@ -113,7 +114,12 @@ class iresnet(nn.Module):
             out_scale.insert(0, lvl)
         r_pr2, r_pr1, r_pr0 = keep[2], keep[1], keep[0]
         for _ in range(iter):
-            err = torch.abs(stemL - imwrap_BCHW(stemR, -r_pr0))
+            if stemL.is_cuda and not torch.is_grad_enabled():
+                # one HIP pass; the epsilon is drawn exactly as the reference draws it (imwrap.py:70)
+                delt = float(1e-4 * (torch.rand(1)[0] + 0.1))
+                err = cv.warp_abs_error(stemL, stemR, -r_pr0, delt)
+            else:
+                err = torch.abs(stemL - imwrap_BCHW(stemR, -r_pr0))
             r_conv0 = self.r_conv0(myCat2d(err, r_pr0, stemL))
             r_conv1 = self.r_conv1(r_conv0)
             r_corr = self.r_corr(self.c_conv1(conv1L), self.c_conv1(conv1R))

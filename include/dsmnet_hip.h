@@ -210,6 +210,15 @@ int dsm_spp_branches(const void* p8, const void* w_t, const void* scale, const v
 int dsm_spp_concat(const void* raw, const void* skip, const void* branches, void* out,
                    int B, int H, int W, dsm_stream_t stream);
 
+/* Disparity warp, optionally fused with the reconstruction error -- utils/imwrap.py:37-72
+ * (imwrap_BCHW with its default arguments) and models/iresnet.py:169-170.
+ *   R (B,C,H0,W0), disp (B,1,H,W), out (B,C,H,W), all NCHW fp32;
+ *   out = grid_sample(R + delt, grid(disp), bilinear, zeros, align_corners=False)
+ *   L (B,C,H,W) non-NULL: out = |L - that|.  delt: the reference's random epsilon, drawn by the
+ *   caller (1e-4 * (U[0,1) + 0.1)). */
+int dsm_warp_abs_error(const void* L, const void* R, const void* disp, void* out, int B, int C,
+                       int H, int W, int H0, int W0, float delt, dsm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
