@@ -451,6 +451,287 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
 }
 
 // ----------------------------------------------------------------------------
+// fp32 convolution on the bf16 matrix pipe ("bf16x3"): Conv3d k3 s1 p1, Cout = 32, Cin % 16 == 0.
+//
+// The fp32-input MFMA runs at the vector rate (157 TF/s, 1/16 of bf16) and is the wall of this
+// path.  Here every fp32 operand is split EXACTLY into three bf16 terms,
+//     v = hi + mid + lo,   hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid)
+// (round-to-nearest; the two subtractions are exact in fp32, so the three terms carry all 24
+// bits of v up to a final rounding of 2^-25 |v|), and a product is evaluated as the six largest
+// of the nine cross terms
+//     w*x ~= wh*xh + wh*xm + wm*xh + wh*xl + wl*xh + wm*xm
+// on v_mfma_f32_32x32x16_bf16: every bf16 x bf16 product is exact in the fp32 accumulator, the
+// three dropped terms are <= 3 * 2^-25 |w*x| (below the rounding of an fp32 fma chain of this
+// length), and accumulation is fp32.  Six MFMAs at 16x the fp32 rate = 2.67x the throughput at
+// fp32 accuracy -- parity tests run at the same tolerances as the fp32 kernel.
+//
+// Structure: workgroup = 4 waves = output tile 1 z x 16 y x 32 x; wave w owns rows 4w..4w+3 (four
+// 32x32 accumulators).  A chunk = one z-tap plane x 16 input channels: its (18 x 34)-voxel halo is
+// staged global -> VGPR (fp32, buffer loads with zero address VALU as above) -> split -> LDS as
+// [voxel][plane 3][16 bf16] at a pitch of 7 x 16 B (conflict-free ds_read_b128 for the 16-lane
+// read groups).  Per tap: 3 weight fragments (buffer loads, 2 items ahead, the ring running on
+// across chunks) and per row 3 activation fragments (LDS) feed 6 MFMAs.
+// One workgroup per CU, one wave per SIMD, TWO LDS images: the next chunk is loaded, split and
+// written into the other image from inside this chunk's MFMA stream -- half an element (11 VALU
+// + 3 ds_write_b64) per 6-MFMA group, in the wave's own issue gaps (a 32x32x16 MFMA holds vector
+// issue for 8 of its 32 cycles).  Measured on the first version (one image, two workgroups per
+// CU, split at the commit between two barriers): VALU beside a PARTNER wave's MFMA stream
+// issues about once per MFMA -- the commit took 18-21 % of every wave's time -- which is the same
+// effect that shaped the fp32 kernel above.  One barrier per chunk is left.
+// Weights: pre-split, section 2 of the packed buffer, [Cin/16][dz][tap9][plane][lane][8 bf16].
+// ----------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {        // low half = a
+  const f32x2 t = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// four fp32 -> three planes of four bf16 (8 bytes each)
+__device__ __forceinline__ void split3(const f32x4 v, u32x2 (&pl)[3]) {
+  float r0 = v.x, r1 = v.y, r2 = v.z, r3 = v.w;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const unsigned a = pack_bf16(r0, r1), b = pack_bf16(r2, r3);
+    pl[k].x = a; pl[k].y = b;
+    if (k < 2) { r0 -= bf16_lo(a); r1 -= bf16_hi(a); r2 -= bf16_lo(b); r3 -= bf16_hi(b); }
+  }
+}
+
+__global__ __launch_bounds__(NTHREADS, 1) void conv3d_bf16x3_kernel(ConvParams p) {
+  constexpr int TM = 4, TY = 16, IY = TY + 2, IX = 34, NQ = 4, CK = 16;
+  constexpr int NVOX = IY * IX;                 // 612
+  constexpr int NE = NVOX * NQ;                 // 2448 staged 16-B fp32 quads per chunk
+  constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;   // 10
+  constexpr int PITCH = 112;                    // bytes per voxel in LDS: 3 planes x 32 B + 16 pad
+  constexpr int IMG = NPF * 64 * PITCH;         // 71,680 B: 640 voxels, the tail quads land in padding
+  constexpr int NITEM = 9;
+  constexpr int AHEAD = 3;                      // weight ring: two items ahead (eight measured the same)
+  constexpr int CONV0 = 3 * TM;                 // first (item, row) slot that converts: item 3
+  constexpr unsigned OOB = 0xfffffff0u;         // beyond any tensor: the buffer load returns zeros
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nch = p.Cin / CK;
+
+  int step, end;
+  int t = first_tile(p.ntiles, step, end);
+  if (t >= end) return;
+
+  // Staging is branch-free: element k of this thread sits at voxel (yy, xx) of the halo box;
+  // its byte offset from the box origin is fixed per launch, and a voxel outside the volume is
+  // read through the buffer descriptor at an out-of-range offset (hardware returns zeros).
+  f32x4 pf[NPF];
+  unsigned goff[NPF], yx[NPF];
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) {
+    const int e = tid + k * NTHREADS;
+    const int v = e / NQ, q = e % NQ;
+    const int yy = v / IX, xx = v % IX;
+    goff[k] = 4u * (unsigned)((yy * p.Wi + xx) * p.Cin + 4 * q);
+    yx[k] = e < NE ? ((unsigned)yy << 16 | (unsigned)xx) : 0x7fff0000u;   // tail: never in range
+  }
+  const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(p.x, p.xbytes);
+  const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.wbytes);
+  const unsigned plane_bytes = 4u * (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)p.Cin;
+
+  // (tile, dz, ck) of the chunk being multiplied and of the one being staged
+  struct Pos { int t, dz, ck, yb, xb, z; unsigned base; };   // base: byte offset of the box origin at dz = 0, ck = 0 (mod 2^32)
+  auto tile_pos = [&](int id) {
+    Pos q; q.t = id; q.dz = 0; q.ck = 0;
+    q.xb = (id % p.ntx) * 32 - 1; id /= p.ntx;
+    q.yb = (id % p.nty) * TY - 1; id /= p.nty;
+    q.z = id % p.Do; const int b = id / p.Do;
+    q.base = (unsigned)(4l * (((((long)b * p.Di + (q.z - 1)) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
+    return q;
+  };
+  auto advance = [&](Pos q) {                   // next chunk: ck fastest, then dz, then the tile
+    if (++q.ck == nch) { q.ck = 0; if (++q.dz == 3) q = tile_pos(q.t + step); }
+    return q;
+  };
+  auto stage = [&](auto kc, const Pos& q, bool live) {
+    constexpr int k = decltype(kc)::value;
+    const int y = q.yb + (int)(yx[k] >> 16), x = q.xb + (int)(yx[k] & 0xffffu);
+    const bool ok = live && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+    const unsigned off = q.base + (unsigned)q.dz * plane_bytes + (unsigned)q.ck * (CK * 4) + goff[k];
+    pf[k] = buffer_load16(xrsrc, ok ? off : OOB, 0);
+  };
+  auto live_of = [&](const Pos& q) {            // wave-uniform: a tile exists and its z-tap plane is inside
+    const int zin = q.z + q.dz - 1;
+    return q.t < end && zin >= 0 && zin < p.Di;
+  };
+  auto wbase_of = [&](const Pos& q) { return (unsigned)((q.ck * 3 + q.dz) * 9) * (3 * 64 * 16); };
+
+  // LDS write address of this thread's quad k: voxel (tid >> 2) + 64 k, channels 4 (tid & 3)..
+  const int wr_off = (tid >> 2) * PITCH + (tid & 3) * 8;
+  // this lane's activation fragment: voxel (row 4 wave + m + dy, column r + dx), half h
+  const int rd_off = ((wave * TM) * IX + r) * PITCH + h * 16;
+
+  f32x16 acc[TM];
+  const Affine af = load_affine(p.scale, p.shift, 4 * h);
+  const unsigned lane16 = lane * 16u;
+  static_assert(NITEM % AHEAD == 0, "continuous weight ring");
+  bf16x8 wq[AHEAD][3];
+  unsigned half_a[3];                           // first channel pair of the element being split
+
+  // One element (4 channels of one voxel) -> image, split in two halves so that each rides in
+  // the gaps of one 6-MFMA group.
+  auto convert = [&](auto kc, auto hc, unsigned char* img) {
+    constexpr int k = decltype(kc)::value, half = decltype(hc)::value;
+    float r0 = half ? pf[k].z : pf[k].x, r1 = half ? pf[k].w : pf[k].y;
+    unsigned pl[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      pl[q] = pack_bf16(r0, r1);
+      if (q < 2) { r0 -= bf16_lo(pl[q]); r1 -= bf16_hi(pl[q]); }
+    }
+    if constexpr (half == 0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) half_a[q] = pl[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        u32x2 v; v.x = half_a[q]; v.y = pl[q];
+        *reinterpret_cast<u32x2*>(img + wr_off + k * (64 * PITCH) + q * 32) = v;
+      }
+    }
+  };
+
+  Pos cur_pos = tile_pos(t);
+  {                                             // first chunk of the launch: staged synchronously
+    const bool live = live_of(cur_pos);
+    static_for<0, NPF>([&](auto kc) { stage(kc, cur_pos, live); });
+    static_for<0, AHEAD - 1>([&](auto ic) {
+      constexpr int item = decltype(ic)::value;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        wq[item % AHEAD][q] = __builtin_bit_cast(
+            bf16x8, buffer_load16(wrsrc, lane16, (item * 3 + q) * (64 * 16)));
+    });
+    static_for<0, NPF>([&](auto kc) {
+      convert(kc, std::integral_constant<int, 0>{}, lds_raw);
+      convert(kc, std::integral_constant<int, 1>{}, lds_raw);
+    });
+  }
+  int cur = 0;                                  // image holding the current chunk
+  DSM_STAMP_INIT();
+  while (true) {
+    __syncthreads();            // image `cur` is complete; everyone is done reading image `cur ^ 1`
+    DSM_STAMP(0);
+    const unsigned char* const rd = lds_raw + cur * IMG + rd_off;
+    unsigned char* const nimg = lds_raw + (cur ^ 1) * IMG;
+    const Pos nxt = advance(cur_pos);
+    const bool nlive = live_of(nxt);
+    if (cur_pos.dz == 0 && cur_pos.ck == 0) {
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+    }
+    const unsigned wchunk = wbase_of(cur_pos), wnext = nxt.t < end ? wbase_of(nxt) : 0u;
+    bf16x8 xq[2][3];
+    auto wload = [&](auto ic, unsigned wb) {
+      constexpr int item = decltype(ic)::value;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        wq[item % AHEAD][q] = __builtin_bit_cast(
+            bf16x8, buffer_load16(wrsrc, lane16, wb + (item * 3 + q) * (64 * 16)));
+    };
+    auto xload = [&](auto sc) {                 // s = item * TM + m
+      constexpr int s = decltype(sc)::value;
+      constexpr int item = s / TM, m = s % TM;
+      constexpr int dy = item / 3, dx = item % 3;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        xq[s & 1][q] = *reinterpret_cast<const bf16x8*>(rd + ((m + dy) * IX + dx) * PITCH + q * 32);
+    };
+    DSM_STAMP(3);
+    xload(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    DSM_STAMP(7);
+    static_for<0, NITEM>([&](auto ic) {
+      constexpr int item = decltype(ic)::value;
+      // the weight ring runs on into the next chunk (NITEM % AHEAD == 0 keeps the slots aligned)
+      if constexpr (item + AHEAD - 1 < NITEM) wload(std::integral_constant<int, item + AHEAD - 1>{}, wchunk);
+      else wload(std::integral_constant<int, item + AHEAD - 1 - NITEM>{}, wnext);
+      static_for<0, TM>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int s = item * TM + m;
+        if constexpr (s + 1 < NITEM * TM) xload(std::integral_constant<int, s + 1>{});
+        // staged loads of the next chunk: one per 6-MFMA group over the first ten groups
+        if constexpr (s < NPF) stage(std::integral_constant<int, s>{}, nxt, nlive);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 wh = wq[item % AHEAD][0], wm = wq[item % AHEAD][1], wl = wq[item % AHEAD][2];
+        const bf16x8 xh = xq[s & 1][0], xm = xq[s & 1][1], xl = xq[s & 1][2];
+        // A operand = weights (rows: channels), B operand = activations (columns: voxels);
+        // small terms first
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[m], 0, 0, 0);
+        // split half an element of the next chunk into the other image, in this group's gaps:
+        // element j was requested in group j and is converted in groups 12 + 2j, 13 + 2j
+        if constexpr (s >= CONV0 && s < CONV0 + 2 * NPF)
+          convert(std::integral_constant<int, (s - CONV0) / 2>{},
+                  std::integral_constant<int, (s - CONV0) % 2>{}, nimg);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    DSM_STAMP(4);
+    if (cur_pos.dz == 2 && cur_pos.ck == nch - 1) {          // epilogue
+      int id = cur_pos.t;
+      const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
+      const int ty0 = (id % p.nty) * TY; id /= p.nty;
+      const int tz = id % p.Do, tb = id / p.Do;
+      const int xo = tx0 + r;
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        const int yo = ty0 + wave * TM + m;
+        if (yo >= p.Ho || xo >= p.Wo) continue;
+        const long vox = (((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo;
+        const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
+        store_tile<32>(acc[m], af, p.relu, p.y + vox * 32 + 4 * h,
+                       p.res ? p.res + rvox * 32 + 4 * h : nullptr);
+      }
+    }
+    DSM_STAMP(5);
+    cur_pos = nxt; cur ^= 1;
+    if (cur_pos.t >= end) break;
+  }
+}
+
+// weights -> section 2 of the packed buffer: [Cin/16][dz][tap9][plane][lane][8 bf16]
+__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                           int Cin, int Cout, int transposed) {
+  const long n = (long)Cin * Cout * 27;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  long i = idx;
+  const int j = i & 7; i >>= 3;
+  const int lane = i & 63; i >>= 6;
+  const int tap = i % 27; const int c16 = i / 27;           // tap = dz * 9 + t9
+  const int cin = 16 * c16 + 8 * (lane >> 5) + j, cout = lane & 31;
+  const long src = transposed ? (((long)cin * Cout + cout) * 27 + tap)
+                              : (((long)cout * Cin + cin) * 27 + tap);
+  float v = w[src];
+  unsigned short* o = out + ((((long)c16 * 27 + tap) * 3) * 64 + lane) * 8 + j;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const unsigned u = pack_bf16(v, 0.f);
+    o[(long)q * 64 * 8] = (unsigned short)(u & 0xffffu);
+    v -= bf16_lo(u);
+  }
+}
+
+// ----------------------------------------------------------------------------
 // ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1), Cout = 32*NT.
 //   out[o] += in[i] * w[k],  o = 2i - 1 + k   per dimension, so an output of parity
 //   0 (o = 2m) has one tap (k=1, i=m) and of parity 1 (o = 2m+1) two taps
@@ -988,6 +1269,28 @@ int run_conv(ConvParams p, hipStream_t s) {
   return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK, KZ, KXY, DIL>, p, lds, s, 512);
 }
 
+int run_conv_bf16x3(ConvParams p, hipStream_t s) {
+  p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, 16);
+  const long nt = (long)p.B * p.Do * p.nty * p.ntx;
+  if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
+  p.ntiles = (int)nt;
+  const size_t lds = (size_t)2 * 10 * 64 * 112;                      // two images: 140 KB, one workgroup per CU
+  return launch_tiles(conv3d_bf16x3_kernel, p, lds, s, 256);
+}
+
+// Section 2 of a packed weight buffer (the pre-split bf16 planes): only for the shapes
+// conv3d_bf16x3_kernel covers.
+size_t bf16x3_section_bytes(int Cin, int Cout) {
+  return (Cout == 32 && Cin % 16 == 0) ? (size_t)Cin * Cout * 27 * 6 : 0;
+}
+
+// DSM_CONV_PRECISION=fp32 keeps every convolution on the fp32-input MFMA (A/B and parity runs).
+bool bf16x3_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("DSM_CONV_PRECISION"); on = !(e && e[0] == 'f'); }
+  return on != 0;
+}
+
 template <int NT, int CK>
 int run_deconv(ConvParams p, hipStream_t s) {
   constexpr int TY = 4;
@@ -1004,7 +1307,7 @@ int run_deconv(ConvParams p, hipStream_t s) {
 extern "C" size_t dsm_conv3d_packed_weight_bytes(int Cin, int Cout, int transposed) {
   (void)transposed;
   if (Cin <= 0 || Cout <= 0) return 0;
-  return (size_t)Cin * Cout * 27 * sizeof(float);
+  return (size_t)Cin * Cout * 27 * sizeof(float) + bf16x3_section_bytes(Cin, Cout);
 }
 
 extern "C" int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed, int Cin, int Cout,
@@ -1017,6 +1320,10 @@ extern "C" int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed, int 
   hipLaunchKernelGGL(pack_weights_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const float*)w_torch, (float*)w_packed, Cin, Cout,
                      transposed, 27, Cin);
+  if (bf16x3_section_bytes(Cin, Cout))
+    hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)w_torch,
+                       (unsigned short*)((float*)w_packed + n), Cin, Cout, transposed);
   return dsm_launch_status();
 }
 
@@ -1037,7 +1344,7 @@ extern "C" int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Ci
 
 namespace {
 // One place decides the kernel variant; dsm_conv3d_fwd launches it, dsm_conv3d_plan names it.
-struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1, 4 conv cout1 z-sliding
+struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1, 4 conv cout1 z-sliding, 5 conv bf16x3
 
 int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   DSM_REQUIRE(a && a->x && a->w_packed && a->y, DSM_ERR_ARG);
@@ -1089,6 +1396,10 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
     *pl = Plan{0, a->stride, NT, TM, 16, 1, k, dil};
     return DSM_OK;
   }
+  if (a->stride == 1 && NT == 1 && bf16x3_enabled()) {
+    *pl = Plan{5, 1, 1, 4, 16, 3, 3, 1};
+    return DSM_OK;
+  }
   if (a->stride == 1) {
     static int force_tm = -1;                      // DSM_CONV3D_TM=1|2: tile-height A/B runs
     if (force_tm < 0) { const char* e = getenv("DSM_CONV3D_TM"); force_tm = e ? atoi(e) : 0; }
@@ -1114,6 +1425,7 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
     case 1: snprintf(buf, len, "deconv3d_mfma_kernel<NT=%d,CK=%d>", pl.NT, pl.CK); break;
     case 2: snprintf(buf, len, "conv3d_cout1_kernel<CK=%d>", pl.CK); break;
     case 4: snprintf(buf, len, "conv3d_cout1_zslide_kernel"); break;
+    case 5: snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<NT=%d>", pl.NT); break;
     default: snprintf(buf, len, "deconv3d_cout1_kernel"); break;
   }
   return DSM_OK;
@@ -1146,6 +1458,11 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
     const size_t lds = (size_t)(2 * 5 * 33 * 8 + 27 * 8) * 16;     // 45.7 KB
     hipLaunchKernelGGL(deconv3d_cout1_kernel, dim3((unsigned)nt), dim3(NTHREADS), lds, s, p);
     return dsm_launch_status();
+  }
+  if (pl.kind == 5) {
+    p.w = (const float*)a->w_packed + (size_t)a->Cin * a->Cout * 27;      // section 2
+    p.wbytes = (unsigned)bf16x3_section_bytes(a->Cin, a->Cout);
+    return run_conv_bf16x3(p, s);
   }
   if (pl.kind == 4) {
     p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, 8);

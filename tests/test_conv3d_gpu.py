@@ -111,3 +111,40 @@ def test_relayout_roundtrip(cv):
     assert cl.is_contiguous(memory_format=torch.channels_last_3d) and torch.equal(cl, x)
     back = cv.to_contiguous_3d(cl)
     assert back.is_contiguous() and torch.equal(back, x)
+
+
+def test_bf16x3_split_agrees_with_fp32_mfma(cv):
+    """The bf16x3 kernel (fp32 operands split exactly into three bf16 terms, six MFMAs per
+    product, fp32 accumulate) against the fp32-input MFMA kernel on the same packed weights:
+    a subprocess per mode, since the precision switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, ".")
+from dsmnet_amd import costvolume as cv
+torch.manual_seed(0)
+x = (torch.randn(1, 32, 20, 37, 70, device="cuda") * 3).contiguous(memory_format=torch.channels_last_3d)
+w = torch.randn(32, 32, 3, 3, 3, device="cuda") * 0.05
+y = cv.conv3d_block(x, cv.pack_conv3d_weight(w, False), 32, None, None, None, 1, False, 0)
+torch.save(y.cpu(), sys.argv[1])
+'''
+    outs = {}
+    for mode in ("fp32", "bf16x3"):
+        path = "/tmp/dsm_prec_%s_%d.pt" % (mode, os.getpid())
+        env = dict(os.environ, DSM_CONV_PRECISION=mode)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        outs[mode] = torch.load(path, weights_only=True)
+        os.remove(path)
+    a, b = outs["fp32"], outs["bf16x3"]
+    ref = torch.nn.functional.conv3d(
+        (torch.manual_seed(0), torch.randn(1, 32, 20, 37, 70, device="cuda") * 3)[1].double().cpu(),
+        (torch.randn(32, 32, 3, 3, 3, device="cuda") * 0.05).double().cpu(), padding=1)
+    scale = ref.abs().max().item()
+    e_fp32, e_split = (a.double() - ref).abs().max().item(), (b.double() - ref).abs().max().item()
+    # both within a few fp32 ulps of the float64 result at this reduction length (K = 864) ...
+    assert e_fp32 <= 2e-6 * scale and e_split <= 2e-6 * scale, (e_fp32, e_split, scale)
+    # ... and the split path is not allowed to be meaningfully worse than the fp32 MFMA
+    assert e_split <= 4 * max(e_fp32, 1e-7 * scale), (e_fp32, e_split)
