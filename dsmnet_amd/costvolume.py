@@ -364,9 +364,13 @@ def pack_conv2d_weight(weight, cin_padded=None):
         raise ValueError("conv2d_block supports 1x1 and 3x3 kernels, got %dx%d" % (kh, kw))
     cin_p = cin if cin_padded is None else int(cin_padded)
     w = weight.detach().contiguous()
-    packed = torch.empty(cin_p * cout * kh * kw, device=w.device, dtype=torch.float32)
+    lib = _lib.load()
+    nbytes = lib.dsm_conv_packed_weight_bytes(cin_p, cout, 1, kh)
+    if nbytes == 0:
+        raise ValueError("pack_conv2d_weight: unsupported shape %s" % (tuple(weight.shape),))
+    packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
     with torch.cuda.device(w.device):
-        rc = _lib.load().dsm_conv_pack_weights(_p(w), _p(packed), cin, cin_p, cout, 1, kh, _stream())
+        rc = lib.dsm_conv_pack_weights(_p(w), _p(packed), cin, cin_p, cout, 1, kh, _stream())
     _lib.check(rc, "dsm_conv_pack_weights")
     return packed
 

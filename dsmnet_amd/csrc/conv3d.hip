@@ -503,17 +503,23 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2 (&pl)[3]) {
   }
 }
 
-__global__ __launch_bounds__(NTHREADS, 1) void conv3d_bf16x3_kernel(ConvParams p) {
-  constexpr int TM = 4, TY = 16, IY = TY + 2, IX = 34, NQ = 4, CK = 16;
-  constexpr int NVOX = IY * IX;                 // 612
-  constexpr int NE = NVOX * NQ;                 // 2448 staged 16-B fp32 quads per chunk
-  constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;   // 10
+// NT = Cout / 32; TM = 32x32 accumulator rows per wave (tile height 4 TM); KZ = 3: 3x3x3 on
+// volumes, KZ = 1: 3x3 on (B,1,H,W,C) views of NHWC maps; DIL: dilation in (y, x).
+template <int NT, int TM, int KZ, int DIL>
+__global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) {
+  constexpr int TY = 4 * TM, IY = TY + 2 * DIL, IX = 32 + 2 * DIL, NQ = 4, CK = 16;
+  constexpr int NVOX = IY * IX;
+  constexpr int NE = NVOX * NQ;                 // staged 16-B fp32 quads per chunk
+  constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
   constexpr int PITCH = 112;                    // bytes per voxel in LDS: 3 planes x 32 B + 16 pad
-  constexpr int IMG = NPF * 64 * PITCH;         // 71,680 B: 640 voxels, the tail quads land in padding
+  constexpr int IMG = NPF * 64 * PITCH;         // the tail quads land in padding
   constexpr int NITEM = 9;
+  constexpr int NGROUP = NITEM * TM;            // (tap, row) groups of 6 NT MFMAs per chunk
   constexpr int AHEAD = 3;                      // weight ring: two items ahead (eight measured the same)
-  constexpr int CONV0 = 3 * TM;                 // first (item, row) slot that converts: item 3
+  constexpr int CONV0 = NGROUP - 2 * NPF;       // first group that converts (the last one finishes the chunk)
+  static_assert(NPF <= NGROUP && CONV0 >= 2, "staging schedule");
   constexpr unsigned OOB = 0xfffffff0u;         // beyond any tensor: the buffer load returns zeros
+  constexpr int COUT = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -545,14 +551,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_bf16x3_kernel(ConvParams p
   struct Pos { int t, dz, ck, yb, xb, z; unsigned base; };   // base: byte offset of the box origin at dz = 0, ck = 0 (mod 2^32)
   auto tile_pos = [&](int id) {
     Pos q; q.t = id; q.dz = 0; q.ck = 0;
-    q.xb = (id % p.ntx) * 32 - 1; id /= p.ntx;
-    q.yb = (id % p.nty) * TY - 1; id /= p.nty;
+    q.xb = (id % p.ntx) * 32 - DIL; id /= p.ntx;
+    q.yb = (id % p.nty) * TY - DIL; id /= p.nty;
     q.z = id % p.Do; const int b = id / p.Do;
-    q.base = (unsigned)(4l * (((((long)b * p.Di + (q.z - 1)) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
+    q.base = (unsigned)(4l * (((((long)b * p.Di + (q.z - KZ / 2)) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
     return q;
   };
   auto advance = [&](Pos q) {                   // next chunk: ck fastest, then dz, then the tile
-    if (++q.ck == nch) { q.ck = 0; if (++q.dz == 3) q = tile_pos(q.t + step); }
+    if (++q.ck == nch) { q.ck = 0; if (++q.dz == KZ) q = tile_pos(q.t + step); }
     return q;
   };
   auto stage = [&](auto kc, const Pos& q, bool live) {
@@ -563,25 +569,25 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_bf16x3_kernel(ConvParams p
     pf[k] = buffer_load16(xrsrc, ok ? off : OOB, 0);
   };
   auto live_of = [&](const Pos& q) {            // wave-uniform: a tile exists and its z-tap plane is inside
-    const int zin = q.z + q.dz - 1;
+    const int zin = q.z + q.dz - KZ / 2;
     return q.t < end && zin >= 0 && zin < p.Di;
   };
-  auto wbase_of = [&](const Pos& q) { return (unsigned)((q.ck * 3 + q.dz) * 9) * (3 * 64 * 16); };
+  // weights: [ck][dz][tap9][n][plane][lane][16 B]
+  auto wbase_of = [&](const Pos& q) { return (unsigned)((q.ck * KZ + q.dz) * 9) * (NT * 3 * 64 * 16); };
 
   // LDS write address of this thread's quad k: voxel (tid >> 2) + 64 k, channels 4 (tid & 3)..
   const int wr_off = (tid >> 2) * PITCH + (tid & 3) * 8;
-  // this lane's activation fragment: voxel (row 4 wave + m + dy, column r + dx), half h
+  // this lane's activation fragment: voxel (row TM wave + m + dy, column r + dx), half h
   const int rd_off = ((wave * TM) * IX + r) * PITCH + h * 16;
 
-  f32x16 acc[TM];
-  const Affine af = load_affine(p.scale, p.shift, 4 * h);
+  f32x16 acc[TM][NT];
   const unsigned lane16 = lane * 16u;
   static_assert(NITEM % AHEAD == 0, "continuous weight ring");
-  bf16x8 wq[AHEAD][3];
+  bf16x8 wq[AHEAD][NT][3];
   unsigned half_a[3];                           // first channel pair of the element being split
 
   // One element (4 channels of one voxel) -> image, split in two halves so that each rides in
-  // the gaps of one 6-MFMA group.
+  // the gaps of one MFMA group.
   auto convert = [&](auto kc, auto hc, unsigned char* img) {
     constexpr int k = decltype(kc)::value, half = decltype(hc)::value;
     float r0 = half ? pf[k].z : pf[k].x, r1 = half ? pf[k].w : pf[k].y;
@@ -602,18 +608,21 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_bf16x3_kernel(ConvParams p
       }
     }
   };
+  auto wload = [&](auto ic, unsigned wb) {
+    constexpr int item = decltype(ic)::value;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        wq[item % AHEAD][n][q] = __builtin_bit_cast(
+            bf16x8, buffer_load16(wrsrc, lane16, wb + ((item * NT + n) * 3 + q) * (64 * 16)));
+  };
 
   Pos cur_pos = tile_pos(t);
   {                                             // first chunk of the launch: staged synchronously
     const bool live = live_of(cur_pos);
     static_for<0, NPF>([&](auto kc) { stage(kc, cur_pos, live); });
-    static_for<0, AHEAD - 1>([&](auto ic) {
-      constexpr int item = decltype(ic)::value;
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        wq[item % AHEAD][q] = __builtin_bit_cast(
-            bf16x8, buffer_load16(wrsrc, lane16, (item * 3 + q) * (64 * 16)));
-    });
+    static_for<0, AHEAD - 1>([&](auto ic) { wload(ic, 0u); });
     static_for<0, NPF>([&](auto kc) {
       convert(kc, std::integral_constant<int, 0>{}, lds_raw);
       convert(kc, std::integral_constant<int, 1>{}, lds_raw);
@@ -632,21 +641,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_bf16x3_kernel(ConvParams p
 #pragma unroll
       for (int m = 0; m < TM; ++m)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
     }
     const unsigned wchunk = wbase_of(cur_pos), wnext = nxt.t < end ? wbase_of(nxt) : 0u;
     bf16x8 xq[2][3];
-    auto wload = [&](auto ic, unsigned wb) {
-      constexpr int item = decltype(ic)::value;
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        wq[item % AHEAD][q] = __builtin_bit_cast(
-            bf16x8, buffer_load16(wrsrc, lane16, wb + (item * 3 + q) * (64 * 16)));
-    };
     auto xload = [&](auto sc) {                 // s = item * TM + m
       constexpr int s = decltype(sc)::value;
       constexpr int item = s / TM, m = s % TM;
-      constexpr int dy = item / 3, dx = item % 3;
+      constexpr int dy = (item / 3) * DIL, dx = (item % 3) * DIL;
 #pragma unroll
       for (int q = 0; q < 3; ++q)
         xq[s & 1][q] = *reinterpret_cast<const bf16x8*>(rd + ((m + dy) * IX + dx) * PITCH + q * 32);
@@ -663,22 +667,25 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_bf16x3_kernel(ConvParams p
       static_for<0, TM>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         constexpr int s = item * TM + m;
-        if constexpr (s + 1 < NITEM * TM) xload(std::integral_constant<int, s + 1>{});
-        // staged loads of the next chunk: one per 6-MFMA group over the first ten groups
+        if constexpr (s + 1 < NGROUP) xload(std::integral_constant<int, s + 1>{});
+        // staged loads of the next chunk: one per group over the first NPF groups
         if constexpr (s < NPF) stage(std::integral_constant<int, s>{}, nxt, nlive);
         __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 wh = wq[item % AHEAD][0], wm = wq[item % AHEAD][1], wl = wq[item % AHEAD][2];
         const bf16x8 xh = xq[s & 1][0], xm = xq[s & 1][1], xl = xq[s & 1][2];
-        // A operand = weights (rows: channels), B operand = activations (columns: voxels);
-        // small terms first
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const bf16x8 wh = wq[item % AHEAD][n][0], wm = wq[item % AHEAD][n][1], wl = wq[item % AHEAD][n][2];
+          // A operand = weights (rows: channels), B operand = activations (columns: voxels);
+          // small terms first
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[m][n], 0, 0, 0);
+        }
         // split half an element of the next chunk into the other image, in this group's gaps:
-        // element j was requested in group j and is converted in groups 12 + 2j, 13 + 2j
+        // element j was requested in group j and is converted in groups CONV0 + 2j, + 2j + 1
         if constexpr (s >= CONV0 && s < CONV0 + 2 * NPF)
           convert(std::integral_constant<int, (s - CONV0) / 2>{},
                   std::integral_constant<int, (s - CONV0) % 2>{}, nimg);
@@ -686,20 +693,25 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_bf16x3_kernel(ConvParams p
       });
     });
     DSM_STAMP(4);
-    if (cur_pos.dz == 2 && cur_pos.ck == nch - 1) {          // epilogue
+    if (cur_pos.dz == KZ - 1 && cur_pos.ck == nch - 1) {     // epilogue
       int id = cur_pos.t;
       const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
       const int ty0 = (id % p.nty) * TY; id /= p.nty;
       const int tz = id % p.Do, tb = id / p.Do;
       const int xo = tx0 + r;
 #pragma unroll
-      for (int m = 0; m < TM; ++m) {
-        const int yo = ty0 + wave * TM + m;
-        if (yo >= p.Ho || xo >= p.Wo) continue;
-        const long vox = (((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo;
-        const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
-        store_tile<32>(acc[m], af, p.relu, p.y + vox * 32 + 4 * h,
-                       p.res ? p.res + rvox * 32 + 4 * h : nullptr);
+      for (int n = 0; n < NT; ++n) {
+        const int cbase = n * 32 + 4 * h;
+        const Affine af = load_affine(p.scale, p.shift, cbase);
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+          const int yo = ty0 + wave * TM + m;
+          if (yo >= p.Ho || xo >= p.Wo) continue;
+          const long vox = (((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo;
+          const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
+          store_tile<COUT>(acc[m][n], af, p.relu, p.y + vox * COUT + cbase,
+                           p.res ? p.res + rvox * COUT + cbase : nullptr);
+        }
       }
     }
     DSM_STAMP(5);
@@ -708,21 +720,24 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_bf16x3_kernel(ConvParams p
   }
 }
 
-// weights -> section 2 of the packed buffer: [Cin/16][dz][tap9][plane][lane][8 bf16]
+// weights -> section 2 of the packed buffer: [Cin/16][tap][Cout/32][plane][lane][8 bf16],
+// tap = dz * 9 + t9 (ntaps = 27) or t9 (ntaps = 9)
 __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                           int Cin, int Cout, int transposed) {
-  const long n = (long)Cin * Cout * 27;
+                                           int Cin, int Cout, int transposed, int ntaps, int cin_src) {
+  const long n = (long)Cin * Cout * ntaps;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
+  const int NT = Cout / 32;
   long i = idx;
   const int j = i & 7; i >>= 3;
   const int lane = i & 63; i >>= 6;
-  const int tap = i % 27; const int c16 = i / 27;           // tap = dz * 9 + t9
-  const int cin = 16 * c16 + 8 * (lane >> 5) + j, cout = lane & 31;
-  const long src = transposed ? (((long)cin * Cout + cout) * 27 + tap)
-                              : (((long)cout * Cin + cin) * 27 + tap);
-  float v = w[src];
-  unsigned short* o = out + ((((long)c16 * 27 + tap) * 3) * 64 + lane) * 8 + j;
+  const int n_ = i % NT; i /= NT;
+  const int tap = i % ntaps; const int c16 = i / ntaps;
+  const int cin = 16 * c16 + 8 * (lane >> 5) + j, cout = 32 * n_ + (lane & 31);
+  const long src = transposed ? (((long)cin * Cout + cout) * ntaps + tap)
+                              : (((long)cout * cin_src + cin) * ntaps + tap);
+  float v = cin < cin_src ? w[src] : 0.f;
+  unsigned short* o = out + (((((long)c16 * ntaps + tap) * NT + n_) * 3) * 64 + lane) * 8 + j;
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     const unsigned u = pack_bf16(v, 0.f);
@@ -1269,19 +1284,24 @@ int run_conv(ConvParams p, hipStream_t s) {
   return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK, KZ, KXY, DIL>, p, lds, s, 512);
 }
 
+template <int NT, int TM, int KZ, int DIL>
 int run_conv_bf16x3(ConvParams p, hipStream_t s) {
-  p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, 16);
+  constexpr int TY = 4 * TM, IY = TY + 2 * DIL, IX = 32 + 2 * DIL;
+  constexpr int NPF = (IY * IX * 4 + NTHREADS - 1) / NTHREADS;
+  p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, TY);
   const long nt = (long)p.B * p.Do * p.nty * p.ntx;
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
-  const size_t lds = (size_t)2 * 10 * 64 * 112;                      // two images: 140 KB, one workgroup per CU
-  return launch_tiles(conv3d_bf16x3_kernel, p, lds, s, 256);
+  const size_t lds = (size_t)2 * NPF * 64 * 112;                     // two images, one workgroup per CU
+  return launch_tiles(conv_bf16x3_kernel<NT, TM, KZ, DIL>, p, lds, s, 256);
 }
 
-// Section 2 of a packed weight buffer (the pre-split bf16 planes): only for the shapes
-// conv3d_bf16x3_kernel covers.
-size_t bf16x3_section_bytes(int Cin, int Cout) {
-  return (Cout == 32 && Cin % 16 == 0) ? (size_t)Cin * Cout * 27 * 6 : 0;
+// Section 2 of a packed weight buffer (the pre-split bf16 planes), present for the shapes the
+// bf16x3 kernels cover: 3x3x3 with Cout 32/64, 3x3 with Cout 32/64/128; Cin % 16 == 0.
+size_t bf16x3_section_bytes(int Cin, int Cout, int kd, int k) {
+  if (k != 3 || Cin % 16 != 0 || Cout % 32 != 0) return 0;
+  if (kd == 3 ? Cout > 64 : Cout > 128) return 0;
+  return (size_t)Cin * Cout * kd * 9 * 6;
 }
 
 // DSM_CONV_PRECISION=fp32 keeps every convolution on the fp32-input MFMA (A/B and parity runs).
@@ -1307,7 +1327,7 @@ int run_deconv(ConvParams p, hipStream_t s) {
 extern "C" size_t dsm_conv3d_packed_weight_bytes(int Cin, int Cout, int transposed) {
   (void)transposed;
   if (Cin <= 0 || Cout <= 0) return 0;
-  return (size_t)Cin * Cout * 27 * sizeof(float) + bf16x3_section_bytes(Cin, Cout);
+  return (size_t)Cin * Cout * 27 * sizeof(float) + bf16x3_section_bytes(Cin, Cout, 3, 3);
 }
 
 extern "C" int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed, int Cin, int Cout,
@@ -1320,10 +1340,10 @@ extern "C" int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed, int 
   hipLaunchKernelGGL(pack_weights_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const float*)w_torch, (float*)w_packed, Cin, Cout,
                      transposed, 27, Cin);
-  if (bf16x3_section_bytes(Cin, Cout))
+  if (bf16x3_section_bytes(Cin, Cout, 3, 3))
     hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float*)w_torch,
-                       (unsigned short*)((float*)w_packed + n), Cin, Cout, transposed);
+                       (unsigned short*)((float*)w_packed + n), Cin, Cout, transposed, 27, Cin);
   return dsm_launch_status();
 }
 
@@ -1339,7 +1359,17 @@ extern "C" int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Ci
   hipLaunchKernelGGL(pack_weights_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const float*)w_torch, (float*)w_packed, Cin, Cout, 0,
                      ntaps, Cin_src);
+  if (bf16x3_section_bytes(Cin, Cout, kd, k))
+    hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)w_torch,
+                       (unsigned short*)((float*)w_packed + n), Cin, Cout, 0, ntaps, Cin_src);
   return dsm_launch_status();
+}
+
+extern "C" size_t dsm_conv_packed_weight_bytes(int Cin, int Cout, int kd, int k) {
+  if (Cin <= 0 || Cout <= 0) return 0;
+  if (!((kd == 1 || kd == 3) && (k == 1 || k == 3))) return 0;
+  return (size_t)Cin * Cout * kd * k * k * sizeof(float) + bf16x3_section_bytes(Cin, Cout, kd, k);
 }
 
 namespace {
@@ -1391,13 +1421,17 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
     return DSM_OK;
   }
   const bool big = (long)a->B * a->Do * dsm_cdiv(a->Ho, 8) * dsm_cdiv(a->Wo, 32) >= 1024;
+  if (a->stride == 1 && k == 3 && bf16x3_enabled() && bf16x3_section_bytes(a->Cin, a->Cout, kd, k)) {
+    // fp32 on the bf16 pipe.  16-row tiles (TM = 4) when they still give every CU a workgroup,
+    // else 8-row tiles; 64 and 128 output channels always take 8-row tiles (accumulators).
+    const long tiles16 = (long)a->B * a->Do * dsm_cdiv(a->Ho, 16) * dsm_cdiv(a->Wo, 32);
+    const int TM = (kd == 3 && NT == 1 && tiles16 >= 224) ? 4 : 2;
+    *pl = Plan{5, 1, NT, TM, 16, kd, 3, dil};
+    return DSM_OK;
+  }
   if (kd == 1) {                                   // 2-D towers: one staged slice, 16-channel chunks
     const int TM = (big && NT == 1 && a->stride == 1 && k == 3 && dil == 1) ? 2 : 1;
     *pl = Plan{0, a->stride, NT, TM, 16, 1, k, dil};
-    return DSM_OK;
-  }
-  if (a->stride == 1 && NT == 1 && bf16x3_enabled()) {
-    *pl = Plan{5, 1, 1, 4, 16, 3, 3, 1};
     return DSM_OK;
   }
   if (a->stride == 1) {
@@ -1425,7 +1459,10 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
     case 1: snprintf(buf, len, "deconv3d_mfma_kernel<NT=%d,CK=%d>", pl.NT, pl.CK); break;
     case 2: snprintf(buf, len, "conv3d_cout1_kernel<CK=%d>", pl.CK); break;
     case 4: snprintf(buf, len, "conv3d_cout1_zslide_kernel"); break;
-    case 5: snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<NT=%d>", pl.NT); break;
+    case 5:
+      if (pl.KZ == 3) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>", pl.NT, pl.TM);
+      else snprintf(buf, len, "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>", pl.NT, pl.TM, pl.DIL);
+      break;
     default: snprintf(buf, len, "deconv3d_cout1_kernel"); break;
   }
   return DSM_OK;
@@ -1460,9 +1497,15 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
     return dsm_launch_status();
   }
   if (pl.kind == 5) {
-    p.w = (const float*)a->w_packed + (size_t)a->Cin * a->Cout * 27;      // section 2
-    p.wbytes = (unsigned)bf16x3_section_bytes(a->Cin, a->Cout);
-    return run_conv_bf16x3(p, s);
+    p.w = (const float*)a->w_packed + (size_t)a->Cin * a->Cout * pl.KZ * 9;   // section 2
+    p.wbytes = (unsigned)bf16x3_section_bytes(a->Cin, a->Cout, pl.KZ, 3);
+#define DSM_CASE_BF(NT_, TM_, KZ_, DIL_) \
+    if (pl.NT == NT_ && pl.TM == TM_ && pl.KZ == KZ_ && pl.DIL == DIL_) \
+      return run_conv_bf16x3<NT_, TM_, KZ_, DIL_>(p, s)
+    DSM_CASE_BF(1, 4, 3, 1); DSM_CASE_BF(1, 2, 3, 1); DSM_CASE_BF(2, 2, 3, 1);
+    DSM_CASE_BF(1, 2, 1, 1); DSM_CASE_BF(2, 2, 1, 1); DSM_CASE_BF(4, 2, 1, 1); DSM_CASE_BF(4, 2, 1, 2);
+#undef DSM_CASE_BF
+    return DSM_ERR_UNSUPPORTED;
   }
   if (pl.kind == 4) {
     p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, 8);

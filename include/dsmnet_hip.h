@@ -155,7 +155,9 @@ int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed,
 
 /* General packer: kd x k x k taps, torch layout (Cout, Cin_src, [kd,] k, k); input channels
  * Cin_src..Cin-1 are packed as zeros (PSMNet's first convolution: 3 staged as 16).
- * Bytes needed: Cin*Cout*kd*k*k*4. */
+ * Bytes needed: dsm_conv_packed_weight_bytes (the fp32 fragments, Cin*Cout*kd*k*k*4, followed for
+ * 3x3(x3) kernels by the pre-split bf16 planes the bf16x3 kernels read). */
+size_t dsm_conv_packed_weight_bytes(int Cin, int Cout, int kd, int k);
 int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, int Cin, int Cout,
                           int kd, int k, dsm_stream_t stream);
 

@@ -55,7 +55,10 @@ def test_argument_validation_returns_codes(hip_lib):
     assert hip_lib.dsm_conv3d_fwd(ctypes.byref(a), null) == -1          # output larger than natural
     a.Do, a.x = 4, 20
     assert hip_lib.dsm_conv3d_fwd(ctypes.byref(a), null) == -4          # misaligned
-    assert hip_lib.dsm_conv3d_packed_weight_bytes(32, 32, 0) == 32 * 32 * 27 * 4
+    assert hip_lib.dsm_conv3d_packed_weight_bytes(32, 32, 0) == 32 * 32 * 27 * (4 + 6)   # fp32 fragments + 3 bf16 planes
+    assert hip_lib.dsm_conv3d_packed_weight_bytes(128, 128, 0) == 128 * 128 * 27 * 4      # no bf16x3 variant
+    assert hip_lib.dsm_conv_packed_weight_bytes(128, 128, 1, 3) == 128 * 128 * 9 * (4 + 6)
+    assert hip_lib.dsm_conv_packed_weight_bytes(128, 32, 1, 1) == 128 * 32 * 4
 
 
 def test_ops_refuse_cpu_tensors():
