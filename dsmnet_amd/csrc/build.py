@@ -32,7 +32,8 @@ def build(force=False, verbose=True, stamps=False):
     if stamps:
         lib = os.path.join(HERE, "libdsmnet_hip_stamps.so")
         srcs = [os.path.join(HERE, s) for s in SOURCES]
-        cmd = [HIPCC] + FLAGS + ["-DDSM_STAMPS", "-shared", "-o", lib] + srcs
+        extra = ["-DDSM_ABLATE=%s" % os.environ["DSM_ABLATE"]] if os.environ.get("DSM_ABLATE") else []
+        cmd = [HIPCC] + FLAGS + ["-DDSM_STAMPS"] + extra + ["-shared", "-o", lib] + srcs
         print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         return lib

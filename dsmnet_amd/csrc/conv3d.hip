@@ -515,10 +515,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
   constexpr int IMG = NPF * 64 * PITCH;         // the tail quads land in padding
   constexpr int NITEM = 9;
   constexpr int NGROUP = NITEM * TM;            // (tap, row) groups of 6 NT MFMAs per chunk
-  constexpr int AHEAD = 3;                      // weight ring: two items ahead (eight measured the same)
+  constexpr int AHEAD = 3;                      // weight ring: two items ahead (eight measured the same, twice)
   constexpr int CONV0 = NGROUP - 2 * NPF;       // first group that converts (the last one finishes the chunk)
   static_assert(NPF <= NGROUP && CONV0 >= 2, "staging schedule");
-  constexpr unsigned OOB = 0xfffffff0u;         // beyond any tensor: the buffer load returns zeros
   constexpr int COUT = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
@@ -543,30 +542,41 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
     goff[k] = 4u * (unsigned)((yy * p.Wi + xx) * p.Cin + 4 * q);
     yx[k] = e < NE ? ((unsigned)yy << 16 | (unsigned)xx) : 0x7fff0000u;   // tail: never in range
   }
-  const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(p.x, p.xbytes);
   const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.wbytes);
   const unsigned plane_bytes = 4u * (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)p.Cin;
 
   // (tile, dz, ck) of the chunk being multiplied and of the one being staged
-  struct Pos { int t, dz, ck, yb, xb, z; unsigned base; };   // base: byte offset of the box origin at dz = 0, ck = 0 (mod 2^32)
+  struct Pos { int t, dz, ck, yb, xb, z; unsigned base; };   // base: byte offset of the box origin in the tile's own z-plane (mod 2^32)
   auto tile_pos = [&](int id) {
     Pos q; q.t = id; q.dz = 0; q.ck = 0;
     q.xb = (id % p.ntx) * 32 - DIL; id /= p.ntx;
     q.yb = (id % p.nty) * TY - DIL; id /= p.nty;
     q.z = id % p.Do; const int b = id / p.Do;
-    q.base = (unsigned)(4l * (((((long)b * p.Di + (q.z - KZ / 2)) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
+    q.base = (unsigned)(4l * (((((long)b * p.Di + q.z) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
     return q;
   };
   auto advance = [&](Pos q) {                   // next chunk: ck fastest, then dz, then the tile
     if (++q.ck == nch) { q.ck = 0; if (++q.dz == KZ) q = tile_pos(q.t + step); }
     return q;
   };
-  auto stage = [&](auto kc, const Pos& q, bool live) {
-    constexpr int k = decltype(kc)::value;
-    const int y = q.yb + (int)(yx[k] >> 16), x = q.xb + (int)(yx[k] & 0xffffu);
-    const bool ok = live && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
-    const unsigned off = q.base + (unsigned)q.dz * plane_bytes + (unsigned)q.ck * (CK * 4) + goff[k];
-    pf[k] = buffer_load16(xrsrc, ok ? off : OOB, 0);
+  // Per tile: this thread's NPF byte offsets of its voxels in the tile's own z-plane, channel 0
+  // (or OOBV where the voxel lies outside the volume).  Per chunk only the descriptor's base
+  // moves -- by (dz - KZ/2) planes and ck channel groups, a signed 64-bit scalar add -- so a
+  // staged load costs no VALU at all; a chunk whose whole plane is outside the volume gets a
+  // descriptor of zero records (every load returns zeros).
+  constexpr unsigned OOBV = 0x80000000u;
+  unsigned voff[NPF];
+  auto tile_offsets = [&](const Pos& q) {
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      const int y = q.yb + (int)(yx[k] >> 16), x = q.xb + (int)(yx[k] & 0xffffu);
+      const bool ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+      voff[k] = ok ? q.base + goff[k] : OOBV;
+    }
+  };
+  auto chunk_rsrc = [&](const Pos& q, bool live) {
+    const long off = (long)(q.dz - KZ / 2) * (long)plane_bytes + (long)q.ck * (CK * 4);
+    return make_rsrc(reinterpret_cast<const char*>(p.x) + off, live ? p.xbytes : 0u);
   };
   auto live_of = [&](const Pos& q) {            // wave-uniform: a tile exists and its z-tap plane is inside
     const int zin = q.z + q.dz - KZ / 2;
@@ -619,9 +629,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
   };
 
   Pos cur_pos = tile_pos(t);
+  tile_offsets(cur_pos);
   {                                             // first chunk of the launch: staged synchronously
-    const bool live = live_of(cur_pos);
-    static_for<0, NPF>([&](auto kc) { stage(kc, cur_pos, live); });
+    const __amdgpu_buffer_rsrc_t rs0 = chunk_rsrc(cur_pos, live_of(cur_pos));
+    static_for<0, NPF>([&](auto kc) {
+      pf[decltype(kc)::value] = buffer_load16(rs0, voff[decltype(kc)::value], 0);
+    });
     static_for<0, AHEAD - 1>([&](auto ic) { wload(ic, 0u); });
     static_for<0, NPF>([&](auto kc) {
       convert(kc, std::integral_constant<int, 0>{}, lds_raw);
@@ -636,7 +649,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
     const unsigned char* const rd = lds_raw + cur * IMG + rd_off;
     unsigned char* const nimg = lds_raw + (cur ^ 1) * IMG;
     const Pos nxt = advance(cur_pos);
-    const bool nlive = live_of(nxt);
+    if (nxt.dz == 0 && nxt.ck == 0) tile_offsets(nxt);      // the staged chunk opens a new tile
+    const __amdgpu_buffer_rsrc_t nrsrc = chunk_rsrc(nxt, live_of(nxt));
     if (cur_pos.dz == 0 && cur_pos.ck == 0) {
 #pragma unroll
       for (int m = 0; m < TM; ++m)
@@ -667,9 +681,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
       static_for<0, TM>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         constexpr int s = item * TM + m;
+#if !(defined(DSM_ABLATE) && DSM_ABLATE == 4)
         if constexpr (s + 1 < NGROUP) xload(std::integral_constant<int, s + 1>{});
+#endif
         // staged loads of the next chunk: one per group over the first NPF groups
-        if constexpr (s < NPF) stage(std::integral_constant<int, s>{}, nxt, nlive);
+#if !(defined(DSM_ABLATE) && DSM_ABLATE == 2)
+        if constexpr (s < NPF) pf[s] = buffer_load16(nrsrc, voff[s], 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         const bf16x8 xh = xq[s & 1][0], xm = xq[s & 1][1], xl = xq[s & 1][2];
 #pragma unroll
@@ -686,14 +704,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
         }
         // split half an element of the next chunk into the other image, in this group's gaps:
         // element j was requested in group j and is converted in groups CONV0 + 2j, + 2j + 1
+#if !(defined(DSM_ABLATE) && DSM_ABLATE == 1)
         if constexpr (s >= CONV0 && s < CONV0 + 2 * NPF)
           convert(std::integral_constant<int, (s - CONV0) / 2>{},
                   std::integral_constant<int, (s - CONV0) % 2>{}, nimg);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       });
     });
     DSM_STAMP(4);
+#if defined(DSM_ABLATE) && DSM_ABLATE == 3
+    if (cur_pos.dz == KZ - 1 && cur_pos.ck == nch - 1 && p.B == 12345) {
+#else
     if (cur_pos.dz == KZ - 1 && cur_pos.ck == nch - 1) {     // epilogue
+#endif
       int id = cur_pos.t;
       const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
       const int ty0 = (id % p.nty) * TY; id /= p.nty;
@@ -1421,11 +1445,15 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
     return DSM_OK;
   }
   const bool big = (long)a->B * a->Do * dsm_cdiv(a->Ho, 8) * dsm_cdiv(a->Wo, 32) >= 1024;
-  if (a->stride == 1 && k == 3 && bf16x3_enabled() && bf16x3_section_bytes(a->Cin, a->Cout, kd, k)) {
+  if (a->stride == 1 && k == 3 && bf16x3_enabled() && bf16x3_section_bytes(a->Cin, a->Cout, kd, k) &&
+      4l * a->B * a->Di * a->Hi * a->Wi * a->Cin < 0x80000000l) {       // OOBV must lie past the tensor
     // fp32 on the bf16 pipe.  16-row tiles (TM = 4) when they still give every CU a workgroup,
     // else 8-row tiles; 64 and 128 output channels always take 8-row tiles (accumulators).
     const long tiles16 = (long)a->B * a->Do * dsm_cdiv(a->Ho, 16) * dsm_cdiv(a->Wo, 32);
-    const int TM = (kd == 3 && NT == 1 && tiles16 >= 224) ? 4 : 2;
+    static int force_tm = -1;                      // DSM_BF16X3_TM=2|4: tile-height A/B runs
+    if (force_tm < 0) { const char* e = getenv("DSM_BF16X3_TM"); force_tm = e ? atoi(e) : 0; }
+    int TM = (kd == 3 && NT == 1 && tiles16 >= 224) ? 4 : 2;
+    if (force_tm == 2 || (force_tm == 4 && kd == 3 && NT == 1)) TM = force_tm;
     *pl = Plan{5, 1, NT, TM, 16, kd, 3, dil};
     return DSM_OK;
   }
