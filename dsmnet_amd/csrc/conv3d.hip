@@ -1449,9 +1449,11 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
       4l * a->B * a->Di * a->Hi * a->Wi * a->Cin < 0x80000000l) {       // OOBV must lie past the tensor
     // fp32 on the bf16 pipe.  16-row tiles (TM = 4) when they still give every CU a workgroup,
     // else 8-row tiles; 64 and 128 output channels always take 8-row tiles (accumulators).
-    const long tiles16 = (long)a->B * a->Do * dsm_cdiv(a->Ho, 16) * dsm_cdiv(a->Wo, 32);
+    // (12-row tiles, which divide 96 rows into exactly 15 rounds instead of 11.25, measured 3 %
+    // slower than 16-row tiles with their tail; 8-row tiles 12 % slower.)
     static int force_tm = -1;                      // DSM_BF16X3_TM=2|4: tile-height A/B runs
     if (force_tm < 0) { const char* e = getenv("DSM_BF16X3_TM"); force_tm = e ? atoi(e) : 0; }
+    const long tiles16 = (long)a->B * a->Do * dsm_cdiv(a->Ho, 16) * dsm_cdiv(a->Wo, 32);
     int TM = (kd == 3 && NT == 1 && tiles16 >= 224) ? 4 : 2;
     if (force_tm == 2 || (force_tm == 4 && kd == 3 && NT == 1)) TM = force_tm;
     *pl = Plan{5, 1, NT, TM, 16, kd, 3, dil};
