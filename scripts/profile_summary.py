@@ -10,7 +10,7 @@ tag, stats_csv, bench_json, prof_json = sys.argv[1:5]
 bench = json.load(open(bench_json))
 prof = json.load(open(prof_json))
 rows = list(csv.DictReader(open(stats_csv)))
-OURS = ("conv3d_mfma", "deconv3d", "cout1", "soft_argmin", "volume_", "pack_weights", "spp_", "corr1d")
+OURS = ("conv3d_mfma", "conv_bf16x3", "deconv3d", "cout1", "soft_argmin", "volume_", "pack_weights", "spp_", "corr1d", "warp_")
 
 
 def short(n):
@@ -25,6 +25,11 @@ def plan_name(n):
         S, NT, TM, CK, KZ, K, DIL = map(int, m.groups())
         return ("conv3d_mfma_kernel<S=%d,NT=%d,TM=%d,CK=%d>" % (S, NT, TM, CK) if KZ == 3 else
                 "conv2d_mfma_kernel<S=%d,NT=%d,TM=%d,K=%d,DIL=%d>" % (S, NT, TM, K, DIL))
+    m = re.match(r"conv_bf16x3_kernel<(\d+), (\d+), (\d+), (\d+)>", n)
+    if m:
+        NT, TM, KZ, DIL = map(int, m.groups())
+        return ("conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>" % (NT, TM) if KZ == 3 else
+                "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>" % (NT, TM, DIL))
     m = re.match(r"deconv3d_mfma_kernel<(\d+), (\d+)>", n)
     if m:
         return "deconv3d_mfma_kernel<NT=%s,CK=%s>" % m.groups()
@@ -53,6 +58,9 @@ for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"])):
 d = bench["roofline"]
 print("\nDominant kernel `%s`: %.1f %s = %.1f %% of the %.1f peak (%d launches/step, %.2f ms/step)."
       % (d["kernel"], d["achieved"], d["unit"], 100 * d["frac"], d["peak"], d["launches_per_step"], d["ms_per_step"]))
+if "bf16_mfma_tflops_executed" in d:
+    print("That peak is the dense bf16 MFMA peak (%.0f TF/s) / 6 MFMAs per fp32 product; executed bf16 MFMA rate %.0f TF/s; "
+          "%.2fx the fp32-input MFMA peak (157.3 TF/s) in algorithmic fp32 FLOP/s." % (d["bf16_mfma_peak"], d["bf16_mfma_tflops_executed"], d["x_fp32_mfma_peak"]))
 v = roofs.get("volume_ndhwc_fwd_kernel")
 if v:
     print("Cost-volume build: %.1f us by in-bench events -> %.0f GB/s = %.1f %% of 8 TB/s (north-star target >= 60 %%), %.1f %% of the 6.29 TB/s copy ceiling; PMC traffic %.1f MB vs %.1f MB algorithmic (profiles/r01_d_pmc.md)."
