@@ -69,3 +69,14 @@ def test_ops_refuse_cpu_tensors():
                lambda: cv.soft_argmin(torch.zeros(1, 4, 2, 8))):
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             fn()
+
+
+def test_graft_entry_build_agrees_with_the_header(hip_lib):
+    """__graft_entry__.build() asserts the ABI version: keep it in step with the header."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "dsmnet_hip.h")).read()
+    version = int(re.search(r"#define DSM_ABI_VERSION (\d+)", header).group(1))
+    entry = open(os.path.join(root, "__graft_entry__.py")).read()
+    assert ("dsm_abi_version() == %d" % version) in entry
+    assert hip_lib.dsm_abi_version() == version
