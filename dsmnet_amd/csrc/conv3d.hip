@@ -106,6 +106,8 @@ struct ConvParams {
   int relu;
   int ntx, nty, ntiles;       // tile grid: x tiles, y tiles, total = B*Do*nty*ntx (x8 classes for deconv)
   unsigned xbytes, wbytes;    // extents of x and w for the buffer descriptors (< 4 GiB)
+  int ntp;                    // Cout / 32 of the layer (packing and output stride); a launch may
+                              // compute only NT of them per workgroup column (blockIdx.y: N-split)
 };
 
 // XCD-aware persistent tile order: workgroups are dealt round-robin over the 8
@@ -320,9 +322,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
   // N-tile), re-read per tile where the accumulators need the registers
   constexpr bool KEEP_AFFINE = (NT * TM <= 2) && (NT == 1);
   Affine af[KEEP_AFFINE ? NT : 1];
+  const int n0 = blockIdx.y * NT;               // first N-tile of this workgroup column (N-split)
   if constexpr (KEEP_AFFINE) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) af[n] = load_affine(p.scale, p.shift, n * 32 + 4 * h);
+    for (int n = 0; n < NT; ++n) af[n] = load_affine(p.scale, p.shift, (n0 + n) * 32 + 4 * h);
   }
   const int lane_el = r * S * NQ + h;           // this lane's element within an image row
   int ck = 0;
@@ -368,7 +371,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
     f32x4 abuf[2][TM];
     // [g][tap][nt][lane]: wave-uniform base (SGPRs) + this lane's fixed 16-B slot, so that a
     // B-fragment load is `global_load_dwordx4 v, v_lane, s[base]` with no address VALU
-    const unsigned wchunk = (unsigned)ck * (NG * NTAP * NT * 64 * 16);   // bytes, wave-uniform
+    const unsigned wchunk = (unsigned)ck * (NG * NTAP * 64 * 16) * (unsigned)p.ntp +
+                            (unsigned)n0 * (64 * 16);                    // bytes, wave-uniform
     const unsigned lane16 = lane * 16u;
     auto bload = [&](auto ic) {
       constexpr int item = decltype(ic)::value;
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
 #pragma unroll
       for (int n = 0; n < NT; ++n)
         bq[item % AHEAD][n] =
-            buffer_load16(wrsrc, lane16, wchunk + (((gi * NTAP + tap) * NT + n) * 64) * 16);
+            buffer_load16(wrsrc, lane16, wchunk + (unsigned)(gi * NTAP + tap) * (64 * 16) * (unsigned)p.ntp + n * (64 * 16));
     };
     auto aload = [&](auto ic) {
       constexpr int item = decltype(ic)::value;
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
     // ---- epilogue after the last chunk of a tile --------------------------------
     if (ck == nch - 1) {
       decode(t);
-      constexpr int COUT = 32 * NT;
+      const int COUT = 32 * p.ntp;                            // channels per voxel in memory
       const int xo = tx0 + r;                                 // this lane's output voxel
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
@@ -432,14 +436,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
         const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          const int cbase = n * 32 + 4 * h;
+          const int cbase = (n0 + n) * 32 + 4 * h;
           if constexpr (KEEP_AFFINE) {
-            store_tile<COUT>(acc[m][n], af[n], p.relu, p.y + vox * COUT + cbase,
-                             p.res ? p.res + rvox * COUT + cbase : nullptr);
+            store_tile<0>(acc[m][n], af[n], p.relu, p.y + vox * COUT + cbase,
+                          p.res ? p.res + rvox * COUT + cbase : nullptr);
           } else {
             const Affine a1 = load_affine(p.scale, p.shift, cbase);
-            store_tile<COUT>(acc[m][n], a1, p.relu, p.y + vox * COUT + cbase,
-                             p.res ? p.res + rvox * COUT + cbase : nullptr);
+            store_tile<0>(acc[m][n], a1, p.relu, p.y + vox * COUT + cbase,
+                          p.res ? p.res + rvox * COUT + cbase : nullptr);
           }
         }
       }
@@ -1274,7 +1278,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 }
 
 template <typename K>
-int launch_tiles(K kernel, const ConvParams& p, size_t lds, hipStream_t s, int max_blocks) {
+int launch_tiles(K kernel, const ConvParams& p, size_t lds, hipStream_t s, int max_blocks, int ny = 1) {
   if (lds > 64 * 1024) {
     static thread_local const void* configured[48];
     static thread_local int nconf = 0;
@@ -1292,12 +1296,15 @@ int launch_tiles(K kernel, const ConvParams& p, size_t lds, hipStream_t s, int m
   if (force_blocks) max_blocks = force_blocks;
   int blocks = p.ntiles < max_blocks ? p.ntiles : max_blocks;
   if (blocks >= 8) blocks &= ~7;                 // whole rounds over the 8 XCDs
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(NTHREADS), lds, s, p);
+  hipLaunchKernelGGL(kernel, dim3(blocks, ny), dim3(NTHREADS), lds, s, p);
   return dsm_launch_status();
 }
 
+// NSPLIT > 1: the layer has NT * NSPLIT N-tiles and each workgroup column (blockIdx.y) computes
+// NT of them -- for the tiny 128-channel layers at the bottom of GCNet's encoder (6 x 8 x 16
+// voxels: 12 tiles), where one workgroup per tile left 244 CUs idle behind a 440k-cycle chain.
 template <int S, int NT, int TM, int CK, int KZ = 3, int KXY = 3, int DIL = 1>
-int run_conv(ConvParams p, hipStream_t s) {
+int run_conv(ConvParams p, hipStream_t s, int nsplit = 1) {
   using G = Geo<S, KZ, KXY, DIL>;
   constexpr int TY = 4 * TM;
   p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, TY);
@@ -1305,7 +1312,8 @@ int run_conv(ConvParams p, hipStream_t s) {
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
   const size_t lds = (size_t)G::IZ * G::IY(TY) * (CK / 4) * G::IX * 16;
-  return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK, KZ, KXY, DIL>, p, lds, s, 512);
+  p.ntp = NT * nsplit;
+  return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK, KZ, KXY, DIL>, p, lds, s, 512 / nsplit, nsplit);
 }
 
 template <int NT, int TM, int KZ, int DIL>
@@ -1398,7 +1406,7 @@ extern "C" size_t dsm_conv_packed_weight_bytes(int Cin, int Cout, int kd, int k)
 
 namespace {
 // One place decides the kernel variant; dsm_conv3d_fwd launches it, dsm_conv3d_plan names it.
-struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1, 4 conv cout1 z-sliding, 5 conv bf16x3
+struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; int nsplit = 1; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1, 4 conv cout1 z-sliding, 5 conv bf16x3
 
 int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   DSM_REQUIRE(a && a->x && a->w_packed && a->y, DSM_ERR_ARG);
@@ -1472,6 +1480,10 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   } else {
     *pl = Plan{0, 2, NT, 1, 8, 3, 3, 1};
   }
+  // N-split: a layer with few tiles and several N-tiles runs the NT = 1 variant with one
+  // workgroup column per N-tile (4x the workgroups, each a quarter as long)
+  const long tiles4 = (long)a->B * a->Do * dsm_cdiv(a->Ho, 4) * dsm_cdiv(a->Wo, 32);
+  if (NT >= 2 && tiles4 <= 64 && pl->TM == 1) { pl->nsplit = NT; pl->NT = 1; }
   return DSM_OK;
 }
 }  // namespace
@@ -1483,7 +1495,8 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
   if (rc != DSM_OK) { buf[0] = 0; return rc; }
   switch (pl.kind) {
     case 0:
-      if (pl.KZ == 3) snprintf(buf, len, "conv3d_mfma_kernel<S=%d,NT=%d,TM=%d,CK=%d>", pl.S, pl.NT, pl.TM, pl.CK);
+      if (pl.KZ == 3 && pl.nsplit > 1) snprintf(buf, len, "conv3d_mfma_kernel<S=%d,NT=%d,TM=%d,CK=%d>x%d", pl.S, pl.NT, pl.TM, pl.CK, pl.nsplit);
+      else if (pl.KZ == 3) snprintf(buf, len, "conv3d_mfma_kernel<S=%d,NT=%d,TM=%d,CK=%d>", pl.S, pl.NT, pl.TM, pl.CK);
       else snprintf(buf, len, "conv2d_mfma_kernel<S=%d,NT=%d,TM=%d,K=%d,DIL=%d>", pl.S, pl.NT, pl.TM, pl.K, pl.DIL);
       break;
     case 1: snprintf(buf, len, "deconv3d_mfma_kernel<NT=%d,CK=%d>", pl.NT, pl.CK); break;
@@ -1573,11 +1586,11 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   DSM_CASE(1, 2, 1, 1, 16, (run_deconv<1, 16>(p, s)));
   DSM_CASE(1, 2, 2, 1, 16, (run_deconv<2, 16>(p, s)));
   DSM_CASE(0, 1, 1, 2, 16, (run_conv<1, 1, 2, 16>(p, s)));
-  DSM_CASE(0, 1, 1, 1, 16, (run_conv<1, 1, 1, 16>(p, s)));
+  DSM_CASE(0, 1, 1, 1, 16, (run_conv<1, 1, 1, 16>(p, s, pl.nsplit)));
   DSM_CASE(0, 1, 2, 2, 8, (run_conv<1, 2, 2, 8>(p, s)));
   DSM_CASE(0, 1, 2, 1, 16, (run_conv<1, 2, 1, 16>(p, s)));
   DSM_CASE(0, 1, 4, 1, 16, (run_conv<1, 4, 1, 16>(p, s)));
-  DSM_CASE(0, 2, 1, 1, 8, (run_conv<2, 1, 1, 8>(p, s)));
+  DSM_CASE(0, 2, 1, 1, 8, (run_conv<2, 1, 1, 8>(p, s, pl.nsplit)));
   DSM_CASE(0, 2, 2, 1, 8, (run_conv<2, 2, 1, 8>(p, s)));
   DSM_CASE(0, 2, 4, 1, 8, (run_conv<2, 4, 1, 8>(p, s)));
 #undef DSM_CASE
