@@ -748,6 +748,231 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
   }
 }
 
+// ----------------------------------------------------------------------------
+// ConvTranspose3d(k3, s2, p1, op1) on the bf16 pipe (bf16x3, as conv_bf16x3_kernel above).
+// Work item = (input tile 4 rows x 32 columns at depth m, z-parity pz), as in
+// deconv3d_mfma_kernel: wave w owns input row w, its four (py, px) output classes are 32x32
+// accumulators.  A chunk = one input z-plane (m, or m + 1 for the second z-tap of an odd output
+// plane) x 32 input channels: a 5 x 33-voxel box, [voxel][k-group 2][plane 3][16 bf16] at a
+// 208-B pitch, two images.  Per chunk 18 (k-group, input offset, class) steps of 6 NT MFMAs:
+// offset (0,0) feeds classes {0,1,2,3}, (0,1) {1,3}, (1,0) {2,3}, (1,1) {3}; one activation
+// fragment set per offset, one weight fragment set per step (ring, two steps ahead, running on
+// across chunks).  Staging and the operand split ride in the MFMA stream exactly as above.
+// ----------------------------------------------------------------------------
+struct DcPair { int o, c; };
+__host__ __device__ constexpr DcPair dc_pair(int j) {
+  constexpr int o_of[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
+  constexpr int c_of[9] = {0, 1, 2, 3, 1, 3, 2, 3, 3};
+  return DcPair{o_of[j], c_of[j]};
+}
+__host__ __device__ constexpr int dc_tap9(int j) {           // ky * 3 + kx of pair j
+  const DcPair q = dc_pair(j);
+  const int py = q.c >> 1, px = q.c & 1, iy = q.o >> 1, ix = q.o & 1;
+  const int ky = py ? (iy ? 0 : 2) : 1, kx = px ? (ix ? 0 : 2) : 1;
+  return ky * 3 + kx;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NTHREADS, 1) void deconv_bf16x3_kernel(ConvParams p) {
+  constexpr int TY = 4, IY = TY + 1, IX = 33, CK = 32;
+  constexpr int NVOX = IY * IX;                 // 165
+  constexpr int NE = NVOX * 8;                  // 1320 staged 16-B fp32 quads per chunk
+  constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;   // 6
+  constexpr int PITCH = 208;                    // 2 k-groups x 3 planes x 32 B + 16 pad
+  constexpr int IMG = NPF * 32 * PITCH;         // 39,936 B
+  constexpr int NSTEP = 18;
+  constexpr int AHEAD = 3;
+  constexpr int CONV0 = NSTEP - 2 * NPF;        // 6
+  constexpr unsigned OOBV = 0x80000000u;
+  constexpr int COUT = 32 * NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nck = p.Cin / CK;
+
+  int step, end;
+  int t = first_tile(p.ntiles, step, end);
+  if (t >= end) return;
+
+  f32x4 pf[NPF];
+  unsigned goff[NPF], yx[NPF], voff[NPF];
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) {
+    const int e = tid + k * NTHREADS;
+    const int v = e >> 3, q8 = e & 7;
+    const int yy = v / IX, xx = v % IX;
+    goff[k] = 4u * (unsigned)((yy * p.Wi + xx) * p.Cin + 4 * q8);
+    yx[k] = e < NE ? ((unsigned)yy << 16 | (unsigned)xx) : 0x7fff0000u;
+  }
+  const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.wbytes);
+  const unsigned plane_bytes = 4u * (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)p.Cin;
+
+  struct Pos { int t, pz, iz, ck, yb, xb, m, b; unsigned base; };
+  auto item_pos = [&](int id) {
+    Pos q; q.t = id; q.pz = id & 1; q.iz = 0; q.ck = 0;
+    id >>= 1;
+    q.xb = (id % p.ntx) * 32; id /= p.ntx;
+    q.yb = (id % p.nty) * TY; id /= p.nty;
+    q.m = id % p.Di; q.b = id / p.Di;
+    q.base = (unsigned)(4l * (((((long)q.b * p.Di + q.m) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
+    return q;
+  };
+  auto advance = [&](Pos q) {                   // ck fastest, then the z-tap plane, then the item
+    if (++q.ck == nck) { q.ck = 0; if (++q.iz > q.pz) q = item_pos(q.t + step); }
+    return q;
+  };
+  auto item_offsets = [&](const Pos& q) {
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      const int y = q.yb + (int)(yx[k] >> 16), x = q.xb + (int)(yx[k] & 0xffffu);
+      voff[k] = (y < p.Hi && x < p.Wi) ? q.base + goff[k] : OOBV;
+    }
+  };
+  auto chunk_rsrc = [&](const Pos& q) {
+    const bool live = q.t < end && q.m + q.iz < p.Di;
+    const long off = (long)q.iz * (long)plane_bytes + (long)q.ck * (CK * 4);
+    return make_rsrc(reinterpret_cast<const char*>(p.x) + off, live ? p.xbytes : 0u);
+  };
+  // weights [Cin/16][tap 27][n][plane][lane][16 B]; z-tap of this chunk: pz = 0 -> kz 1; pz = 1 -> kz 2, then 0
+  auto wbase_of = [&](const Pos& q) {
+    const int kz = q.pz ? (q.iz ? 0 : 2) : 1;
+    return (unsigned)((2 * q.ck * 27 + kz * 9) * NT) * (3 * 64 * 16);
+  };
+  const int wr_off = (tid >> 3) * PITCH + ((tid & 7) >> 2) * 96 + (tid & 3) * 8;
+  const int rd_off = (wave * IX + r) * PITCH + h * 16;
+
+  f32x16 acc[4][NT];
+  const unsigned lane16 = lane * 16u;
+  bf16x8 wq[AHEAD][NT][3];
+  unsigned half_a[3];
+  auto convert = [&](auto kc, auto hc, unsigned char* img) {
+    constexpr int k = decltype(kc)::value, half = decltype(hc)::value;
+    float r0 = half ? pf[k].z : pf[k].x, r1 = half ? pf[k].w : pf[k].y;
+    unsigned pl[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      pl[q] = pack_bf16(r0, r1);
+      if (q < 2) { r0 -= bf16_lo(pl[q]); r1 -= bf16_hi(pl[q]); }
+    }
+    if constexpr (half == 0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) half_a[q] = pl[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        u32x2 v; v.x = half_a[q]; v.y = pl[q];
+        *reinterpret_cast<u32x2*>(img + wr_off + k * (32 * PITCH) + q * 32) = v;
+      }
+    }
+  };
+  // step s = g * 9 + j: k-group g, pair j
+  auto wload = [&](auto sc, unsigned wb) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int g = s / 9, tap9 = dc_tap9(s % 9);
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        wq[s % AHEAD][n][q] = __builtin_bit_cast(
+            bf16x8, buffer_load16(wrsrc, lane16, wb + (((g * 27 + tap9) * NT + n) * 3 + q) * (64 * 16)));
+  };
+
+  Pos cur_pos = item_pos(t);
+  item_offsets(cur_pos);
+  {
+    const __amdgpu_buffer_rsrc_t rs0 = chunk_rsrc(cur_pos);
+    static_for<0, NPF>([&](auto kc) {
+      pf[decltype(kc)::value] = buffer_load16(rs0, voff[decltype(kc)::value], 0);
+    });
+    const unsigned w0 = wbase_of(cur_pos);
+    static_for<0, AHEAD - 1>([&](auto sc) { wload(sc, w0); });
+    static_for<0, NPF>([&](auto kc) {
+      convert(kc, std::integral_constant<int, 0>{}, lds_raw);
+      convert(kc, std::integral_constant<int, 1>{}, lds_raw);
+    });
+  }
+  int cur = 0;
+  while (true) {
+    __syncthreads();
+    const unsigned char* const rd = lds_raw + cur * IMG + rd_off;
+    unsigned char* const nimg = lds_raw + (cur ^ 1) * IMG;
+    const Pos nxt = advance(cur_pos);
+    if (nxt.iz == 0 && nxt.ck == 0) item_offsets(nxt);
+    const __amdgpu_buffer_rsrc_t nrsrc = chunk_rsrc(nxt);
+    if (cur_pos.iz == 0 && cur_pos.ck == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[c][n][i] = 0.f;
+    }
+    const unsigned wchunk = wbase_of(cur_pos), wnext = nxt.t < end ? wbase_of(nxt) : 0u;
+    bf16x8 xq[2][3];
+    // activation fragment set xi = g * 4 + o (k-group, input offset)
+    auto xload = [&](auto xc) {
+      constexpr int xi = decltype(xc)::value;
+      constexpr int g = xi / 4, o = xi % 4, iy = o >> 1, ix = o & 1;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        xq[xi & 1][q] = *reinterpret_cast<const bf16x8*>(rd + (iy * IX + ix) * PITCH + (g * 3 + q) * 32);
+    };
+    xload(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, NSTEP>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int g = s / 9, j = s % 9;
+      constexpr DcPair pr = dc_pair(j);
+      constexpr int xi = g * 4 + pr.o;
+      constexpr bool fresh = (j == 0 || j == 4 || j == 6 || j == 8);
+      if constexpr (s + AHEAD - 1 < NSTEP) wload(std::integral_constant<int, s + AHEAD - 1>{}, wchunk);
+      else wload(std::integral_constant<int, s + AHEAD - 1 - NSTEP>{}, wnext);
+      if constexpr (fresh && xi + 1 < 8) xload(std::integral_constant<int, xi + 1>{});
+      if constexpr (s < NPF) pf[s] = buffer_load16(nrsrc, voff[s], 0);
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8 xh = xq[xi & 1][0], xm = xq[xi & 1][1], xl = xq[xi & 1][2];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const bf16x8 wh = wq[s % AHEAD][n][0], wm = wq[s % AHEAD][n][1], wl = wq[s % AHEAD][n][2];
+        f32x16& a = acc[pr.c][n];
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, a, 0, 0, 0);
+      }
+      if constexpr (s >= CONV0)
+        convert(std::integral_constant<int, (s - CONV0) / 2>{},
+                std::integral_constant<int, (s - CONV0) % 2>{}, nimg);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (cur_pos.iz == cur_pos.pz && cur_pos.ck == nck - 1) {   // epilogue of the item
+      const int zo = 2 * cur_pos.m + cur_pos.pz;
+      const int ym = cur_pos.yb + wave, xm_ = cur_pos.xb + r;  // this lane's input-grid position
+      if (zo < p.Do && ym < p.Hi && xm_ < p.Wi) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int cbase = n * 32 + 4 * h;
+          const Affine af = load_affine(p.scale, p.shift, cbase);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int yo = 2 * ym + (c >> 1), xo = 2 * xm_ + (c & 1);
+            if (yo >= p.Ho || xo >= p.Wo) continue;
+            const long vox = (((long)cur_pos.b * p.Do + zo) * p.Ho + yo) * p.Wo + xo;
+            const long rvox = (((long)cur_pos.b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo;
+            store_tile<COUT>(acc[c][n], af, p.relu, p.y + vox * COUT + cbase,
+                             p.res ? p.res + rvox * COUT + cbase : nullptr);
+          }
+        }
+      }
+    }
+    cur_pos = nxt; cur ^= 1;
+    if (cur_pos.t >= end) break;
+  }
+}
+
 // weights -> section 2 of the packed buffer: [Cin/16][tap][Cout/32][plane][lane][8 bf16],
 // tap = dz * 9 + t9 (ntaps = 27) or t9 (ntaps = 9)
 __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
@@ -1328,6 +1553,16 @@ int run_conv_bf16x3(ConvParams p, hipStream_t s) {
   return launch_tiles(conv_bf16x3_kernel<NT, TM, KZ, DIL>, p, lds, s, 256);
 }
 
+template <int NT>
+int run_deconv_bf16x3(ConvParams p, hipStream_t s) {
+  p.ntx = dsm_cdiv(p.Wi, 32); p.nty = dsm_cdiv(p.Hi, 4);
+  const long nt = (long)p.B * p.Di * p.nty * p.ntx * 2;       // x2: z-parity
+  if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
+  p.ntiles = (int)nt;
+  const size_t lds = (size_t)2 * 6 * 32 * 208;                       // two images, 79.9 KB
+  return launch_tiles(deconv_bf16x3_kernel<NT>, p, lds, s, 256);
+}
+
 // Section 2 of a packed weight buffer (the pre-split bf16 planes), present for the shapes the
 // bf16x3 kernels cover: 3x3x3 with Cout 32/64, 3x3 with Cout 32/64/128; Cin % 16 == 0.
 size_t bf16x3_section_bytes(int Cin, int Cout, int kd, int k) {
@@ -1406,7 +1641,7 @@ extern "C" size_t dsm_conv_packed_weight_bytes(int Cin, int Cout, int kd, int k)
 
 namespace {
 // One place decides the kernel variant; dsm_conv3d_fwd launches it, dsm_conv3d_plan names it.
-struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; int nsplit = 1; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1, 4 conv cout1 z-sliding, 5 conv bf16x3
+struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; int nsplit = 1; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1, 4 conv cout1 z-sliding, 5 conv bf16x3, 6 deconv bf16x3
 
 int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   DSM_REQUIRE(a && a->x && a->w_packed && a->y, DSM_ERR_ARG);
@@ -1447,6 +1682,11 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   const int NT = a->Cout / 32;
   // Tile height: 8 rows (TM = 2) when that still gives every CU two workgroups of work,
   // else 4 rows.  Stride 2 stages 8 channels per chunk so that two workgroups fit a CU.
+  if (a->transposed && NT <= 2 && a->Cin % 32 == 0 && bf16x3_enabled() &&
+      4l * a->B * a->Di * a->Hi * a->Wi * a->Cin < 0x80000000l) {
+    *pl = Plan{6, 2, NT, 1, 32, 3, 3, 1};
+    return DSM_OK;
+  }
   if (a->transposed) {
     DSM_REQUIRE(NT <= 2, DSM_ERR_UNSUPPORTED);   // 4 classes x NT accumulators must fit 256 VGPRs
     *pl = Plan{1, 2, NT, 1, 16, 3, 3, 1};   // (32-channel chunks measured slower: 306 vs 283 us)
@@ -1506,6 +1746,7 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
       if (pl.KZ == 3) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>", pl.NT, pl.TM);
       else snprintf(buf, len, "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>", pl.NT, pl.TM, pl.DIL);
       break;
+    case 6: snprintf(buf, len, "deconv3d_bf16x3_mfma_kernel<NT=%d>", pl.NT); break;
     default: snprintf(buf, len, "deconv3d_cout1_kernel"); break;
   }
   return DSM_OK;
@@ -1538,6 +1779,11 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
     const size_t lds = (size_t)(2 * 5 * 33 * 8 + 27 * 8) * 16;     // 45.7 KB
     hipLaunchKernelGGL(deconv3d_cout1_kernel, dim3((unsigned)nt), dim3(NTHREADS), lds, s, p);
     return dsm_launch_status();
+  }
+  if (pl.kind == 6) {
+    p.w = (const float*)a->w_packed + (size_t)a->Cin * a->Cout * 27;          // section 2
+    p.wbytes = (unsigned)bf16x3_section_bytes(a->Cin, a->Cout, 3, 3);
+    return pl.NT == 1 ? run_deconv_bf16x3<1>(p, s) : run_deconv_bf16x3<2>(p, s);
   }
   if (pl.kind == 5) {
     p.w = (const float*)a->w_packed + (size_t)a->Cin * a->Cout * pl.KZ * 9;   // section 2
