@@ -37,7 +37,7 @@ def build(force=False, verbose=True, stamps=False):
         print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         return lib
-    hdrs = [os.path.join(HERE, "common.hpp"),
+    hdrs = [os.path.join(HERE, "common.hpp"), os.path.join(HERE, "conv_bf16x3.hpp"),
             os.path.join(HERE, "..", "..", "include", "dsmnet_hip.h")]
     srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     objs = []

@@ -454,550 +454,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
   }
 }
 
-// ----------------------------------------------------------------------------
-// fp32 convolution on the bf16 matrix pipe ("bf16x3"): Conv3d k3 s1 p1, Cout = 32, Cin % 16 == 0.
-//
-// The fp32-input MFMA runs at the vector rate (157 TF/s, 1/16 of bf16) and is the wall of this
-// path.  Here every fp32 operand is split EXACTLY into three bf16 terms,
-//     v = hi + mid + lo,   hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid)
-// (round-to-nearest; the two subtractions are exact in fp32, so the three terms carry all 24
-// bits of v up to a final rounding of 2^-25 |v|), and a product is evaluated as the six largest
-// of the nine cross terms
-//     w*x ~= wh*xh + wh*xm + wm*xh + wh*xl + wl*xh + wm*xm
-// on v_mfma_f32_32x32x16_bf16: every bf16 x bf16 product is exact in the fp32 accumulator, the
-// three dropped terms are <= 3 * 2^-25 |w*x| (below the rounding of an fp32 fma chain of this
-// length), and accumulation is fp32.  Six MFMAs at 16x the fp32 rate = 2.67x the throughput at
-// fp32 accuracy -- parity tests run at the same tolerances as the fp32 kernel.
-//
-// Structure: workgroup = 4 waves = output tile 1 z x 16 y x 32 x; wave w owns rows 4w..4w+3 (four
-// 32x32 accumulators).  A chunk = one z-tap plane x 16 input channels: its (18 x 34)-voxel halo is
-// staged global -> VGPR (fp32, buffer loads with zero address VALU as above) -> split -> LDS as
-// [voxel][plane 3][16 bf16] at a pitch of 7 x 16 B (conflict-free ds_read_b128 for the 16-lane
-// read groups).  Per tap: 3 weight fragments (buffer loads, 2 items ahead, the ring running on
-// across chunks) and per row 3 activation fragments (LDS) feed 6 MFMAs.
-// One workgroup per CU, one wave per SIMD, TWO LDS images: the next chunk is loaded, split and
-// written into the other image from inside this chunk's MFMA stream -- half an element (11 VALU
-// + 3 ds_write_b64) per 6-MFMA group, in the wave's own issue gaps (a 32x32x16 MFMA holds vector
-// issue for 8 of its 32 cycles).  Measured on the first version (one image, two workgroups per
-// CU, split at the commit between two barriers): VALU beside a PARTNER wave's MFMA stream
-// issues about once per MFMA -- the commit took 18-21 % of every wave's time -- which is the same
-// effect that shaped the fp32 kernel above.  One barrier per chunk is left.
-// Weights: pre-split, section 2 of the packed buffer, [Cin/16][dz][tap9][plane][lane][8 bf16].
-// ----------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {        // low half = a
-  const f32x2 t = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
-}
-__device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
-
-// four fp32 -> three planes of four bf16 (8 bytes each)
-__device__ __forceinline__ void split3(const f32x4 v, u32x2 (&pl)[3]) {
-  float r0 = v.x, r1 = v.y, r2 = v.z, r3 = v.w;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const unsigned a = pack_bf16(r0, r1), b = pack_bf16(r2, r3);
-    pl[k].x = a; pl[k].y = b;
-    if (k < 2) { r0 -= bf16_lo(a); r1 -= bf16_hi(a); r2 -= bf16_lo(b); r3 -= bf16_hi(b); }
-  }
-}
-
-// NT = Cout / 32; TM = 32x32 accumulator rows per wave (tile height 4 TM); KZ = 3: 3x3x3 on
-// volumes, KZ = 1: 3x3 on (B,1,H,W,C) views of NHWC maps; DIL: dilation in (y, x).
-template <int NT, int TM, int KZ, int DIL>
-__global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) {
-  constexpr int TY = 4 * TM, IY = TY + 2 * DIL, IX = 32 + 2 * DIL, NQ = 4, CK = 16;
-  constexpr int NVOX = IY * IX;
-  constexpr int NE = NVOX * NQ;                 // staged 16-B fp32 quads per chunk
-  constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
-  constexpr int PITCH = 112;                    // bytes per voxel in LDS: 3 planes x 32 B + 16 pad
-  constexpr int IMG = NPF * 64 * PITCH;         // the tail quads land in padding
-  constexpr int NITEM = 9;
-  constexpr int NGROUP = NITEM * TM;            // (tap, row) groups of 6 NT MFMAs per chunk
-  constexpr int AHEAD = 3;                      // weight ring: two items ahead (eight measured the same, twice)
-  constexpr int CONV0 = NGROUP - 2 * NPF;       // first group that converts (the last one finishes the chunk)
-  static_assert(NPF <= NGROUP && CONV0 >= 2, "staging schedule");
-  constexpr int COUT = 32 * NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int nch = p.Cin / CK;
-
-  int step, end;
-  int t = first_tile(p.ntiles, step, end);
-  if (t >= end) return;
-
-  // Staging is branch-free: element k of this thread sits at voxel (yy, xx) of the halo box;
-  // its byte offset from the box origin is fixed per launch, and a voxel outside the volume is
-  // read through the buffer descriptor at an out-of-range offset (hardware returns zeros).
-  f32x4 pf[NPF];
-  unsigned goff[NPF], yx[NPF];
-#pragma unroll
-  for (int k = 0; k < NPF; ++k) {
-    const int e = tid + k * NTHREADS;
-    const int v = e / NQ, q = e % NQ;
-    const int yy = v / IX, xx = v % IX;
-    goff[k] = 4u * (unsigned)((yy * p.Wi + xx) * p.Cin + 4 * q);
-    yx[k] = e < NE ? ((unsigned)yy << 16 | (unsigned)xx) : 0x7fff0000u;   // tail: never in range
-  }
-  const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.wbytes);
-  const unsigned plane_bytes = 4u * (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)p.Cin;
-
-  // (tile, dz, ck) of the chunk being multiplied and of the one being staged
-  struct Pos { int t, dz, ck, yb, xb, z; unsigned base; };   // base: byte offset of the box origin in the tile's own z-plane (mod 2^32)
-  auto tile_pos = [&](int id) {
-    Pos q; q.t = id; q.dz = 0; q.ck = 0;
-    q.xb = (id % p.ntx) * 32 - DIL; id /= p.ntx;
-    q.yb = (id % p.nty) * TY - DIL; id /= p.nty;
-    q.z = id % p.Do; const int b = id / p.Do;
-    q.base = (unsigned)(4l * (((((long)b * p.Di + q.z) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
-    return q;
-  };
-  auto advance = [&](Pos q) {                   // next chunk: ck fastest, then dz, then the tile
-    if (++q.ck == nch) { q.ck = 0; if (++q.dz == KZ) q = tile_pos(q.t + step); }
-    return q;
-  };
-  // Per tile: this thread's NPF byte offsets of its voxels in the tile's own z-plane, channel 0
-  // (or OOBV where the voxel lies outside the volume).  Per chunk only the descriptor's base
-  // moves -- by (dz - KZ/2) planes and ck channel groups, a signed 64-bit scalar add -- so a
-  // staged load costs no VALU at all; a chunk whose whole plane is outside the volume gets a
-  // descriptor of zero records (every load returns zeros).
-  constexpr unsigned OOBV = 0x80000000u;
-  unsigned voff[NPF];
-  auto tile_offsets = [&](const Pos& q) {
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-      const int y = q.yb + (int)(yx[k] >> 16), x = q.xb + (int)(yx[k] & 0xffffu);
-      const bool ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
-      voff[k] = ok ? q.base + goff[k] : OOBV;
-    }
-  };
-  auto chunk_rsrc = [&](const Pos& q, bool live) {
-    const long off = (long)(q.dz - KZ / 2) * (long)plane_bytes + (long)q.ck * (CK * 4);
-    return make_rsrc(reinterpret_cast<const char*>(p.x) + off, live ? p.xbytes : 0u);
-  };
-  auto live_of = [&](const Pos& q) {            // wave-uniform: a tile exists and its z-tap plane is inside
-    const int zin = q.z + q.dz - KZ / 2;
-    return q.t < end && zin >= 0 && zin < p.Di;
-  };
-  // weights: [ck][dz][tap9][n][plane][lane][16 B]
-  auto wbase_of = [&](const Pos& q) { return (unsigned)((q.ck * KZ + q.dz) * 9) * (NT * 3 * 64 * 16); };
-
-  // LDS write address of this thread's quad k: voxel (tid >> 2) + 64 k, channels 4 (tid & 3)..
-  const int wr_off = (tid >> 2) * PITCH + (tid & 3) * 8;
-  // this lane's activation fragment: voxel (row TM wave + m + dy, column r + dx), half h
-  const int rd_off = ((wave * TM) * IX + r) * PITCH + h * 16;
-
-  f32x16 acc[TM][NT];
-  const unsigned lane16 = lane * 16u;
-  static_assert(NITEM % AHEAD == 0, "continuous weight ring");
-  bf16x8 wq[AHEAD][NT][3];
-  unsigned half_a[3];                           // first channel pair of the element being split
-
-  // One element (4 channels of one voxel) -> image, split in two halves so that each rides in
-  // the gaps of one MFMA group.
-  auto convert = [&](auto kc, auto hc, unsigned char* img) {
-    constexpr int k = decltype(kc)::value, half = decltype(hc)::value;
-    float r0 = half ? pf[k].z : pf[k].x, r1 = half ? pf[k].w : pf[k].y;
-    unsigned pl[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      pl[q] = pack_bf16(r0, r1);
-      if (q < 2) { r0 -= bf16_lo(pl[q]); r1 -= bf16_hi(pl[q]); }
-    }
-    if constexpr (half == 0) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) half_a[q] = pl[q];
-    } else {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        u32x2 v; v.x = half_a[q]; v.y = pl[q];
-        *reinterpret_cast<u32x2*>(img + wr_off + k * (64 * PITCH) + q * 32) = v;
-      }
-    }
-  };
-  auto wload = [&](auto ic, unsigned wb) {
-    constexpr int item = decltype(ic)::value;
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        wq[item % AHEAD][n][q] = __builtin_bit_cast(
-            bf16x8, buffer_load16(wrsrc, lane16, wb + ((item * NT + n) * 3 + q) * (64 * 16)));
-  };
-
-  Pos cur_pos = tile_pos(t);
-  tile_offsets(cur_pos);
-  {                                             // first chunk of the launch: staged synchronously
-    const __amdgpu_buffer_rsrc_t rs0 = chunk_rsrc(cur_pos, live_of(cur_pos));
-    static_for<0, NPF>([&](auto kc) {
-      pf[decltype(kc)::value] = buffer_load16(rs0, voff[decltype(kc)::value], 0);
-    });
-    static_for<0, AHEAD - 1>([&](auto ic) { wload(ic, 0u); });
-    static_for<0, NPF>([&](auto kc) {
-      convert(kc, std::integral_constant<int, 0>{}, lds_raw);
-      convert(kc, std::integral_constant<int, 1>{}, lds_raw);
-    });
-  }
-  int cur = 0;                                  // image holding the current chunk
-  DSM_STAMP_INIT();
-  while (true) {
-    __syncthreads();            // image `cur` is complete; everyone is done reading image `cur ^ 1`
-    DSM_STAMP(0);
-    const unsigned char* const rd = lds_raw + cur * IMG + rd_off;
-    unsigned char* const nimg = lds_raw + (cur ^ 1) * IMG;
-    const Pos nxt = advance(cur_pos);
-    if (nxt.dz == 0 && nxt.ck == 0) tile_offsets(nxt);      // the staged chunk opens a new tile
-    const __amdgpu_buffer_rsrc_t nrsrc = chunk_rsrc(nxt, live_of(nxt));
-    if (cur_pos.dz == 0 && cur_pos.ck == 0) {
-#pragma unroll
-      for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
-    }
-    const unsigned wchunk = wbase_of(cur_pos), wnext = nxt.t < end ? wbase_of(nxt) : 0u;
-    bf16x8 xq[2][3];
-    auto xload = [&](auto sc) {                 // s = item * TM + m
-      constexpr int s = decltype(sc)::value;
-      constexpr int item = s / TM, m = s % TM;
-      constexpr int dy = (item / 3) * DIL, dx = (item % 3) * DIL;
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        xq[s & 1][q] = *reinterpret_cast<const bf16x8*>(rd + ((m + dy) * IX + dx) * PITCH + q * 32);
-    };
-    DSM_STAMP(3);
-    xload(std::integral_constant<int, 0>{});
-    __builtin_amdgcn_sched_barrier(0);
-    DSM_STAMP(7);
-    static_for<0, NITEM>([&](auto ic) {
-      constexpr int item = decltype(ic)::value;
-      // the weight ring runs on into the next chunk (NITEM % AHEAD == 0 keeps the slots aligned)
-      if constexpr (item + AHEAD - 1 < NITEM) wload(std::integral_constant<int, item + AHEAD - 1>{}, wchunk);
-      else wload(std::integral_constant<int, item + AHEAD - 1 - NITEM>{}, wnext);
-      static_for<0, TM>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        constexpr int s = item * TM + m;
-#if !(defined(DSM_ABLATE) && DSM_ABLATE == 4)
-        if constexpr (s + 1 < NGROUP) xload(std::integral_constant<int, s + 1>{});
-#endif
-        // staged loads of the next chunk: one per group over the first NPF groups
-#if !(defined(DSM_ABLATE) && DSM_ABLATE == 2)
-        if constexpr (s < NPF) pf[s] = buffer_load16(nrsrc, voff[s], 0);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 xh = xq[s & 1][0], xm = xq[s & 1][1], xl = xq[s & 1][2];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const bf16x8 wh = wq[item % AHEAD][n][0], wm = wq[item % AHEAD][n][1], wl = wq[item % AHEAD][n][2];
-          // A operand = weights (rows: channels), B operand = activations (columns: voxels);
-          // small terms first
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[m][n], 0, 0, 0);
-        }
-        // split half an element of the next chunk into the other image, in this group's gaps:
-        // element j was requested in group j and is converted in groups CONV0 + 2j, + 2j + 1
-#if !(defined(DSM_ABLATE) && DSM_ABLATE == 1)
-        if constexpr (s >= CONV0 && s < CONV0 + 2 * NPF)
-          convert(std::integral_constant<int, (s - CONV0) / 2>{},
-                  std::integral_constant<int, (s - CONV0) % 2>{}, nimg);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    });
-    DSM_STAMP(4);
-#if defined(DSM_ABLATE) && DSM_ABLATE == 3
-    if (cur_pos.dz == KZ - 1 && cur_pos.ck == nch - 1 && p.B == 12345) {
-#else
-    if (cur_pos.dz == KZ - 1 && cur_pos.ck == nch - 1) {     // epilogue
-#endif
-      int id = cur_pos.t;
-      const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
-      const int ty0 = (id % p.nty) * TY; id /= p.nty;
-      const int tz = id % p.Do, tb = id / p.Do;
-      const int xo = tx0 + r;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int cbase = n * 32 + 4 * h;
-        const Affine af = load_affine(p.scale, p.shift, cbase);
-#pragma unroll
-        for (int m = 0; m < TM; ++m) {
-          const int yo = ty0 + wave * TM + m;
-          if (yo >= p.Ho || xo >= p.Wo) continue;
-          const long vox = (((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo;
-          const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
-          store_tile<COUT>(acc[m][n], af, p.relu, p.y + vox * COUT + cbase,
-                           p.res ? p.res + rvox * COUT + cbase : nullptr);
-        }
-      }
-    }
-    DSM_STAMP(5);
-    cur_pos = nxt; cur ^= 1;
-    if (cur_pos.t >= end) break;
-  }
-}
-
-// ----------------------------------------------------------------------------
-// ConvTranspose3d(k3, s2, p1, op1) on the bf16 pipe (bf16x3, as conv_bf16x3_kernel above).
-// Work item = (input tile 4 rows x 32 columns at depth m, z-parity pz), as in
-// deconv3d_mfma_kernel: wave w owns input row w, its four (py, px) output classes are 32x32
-// accumulators.  A chunk = one input z-plane (m, or m + 1 for the second z-tap of an odd output
-// plane) x 32 input channels: a 5 x 33-voxel box, [voxel][k-group 2][plane 3][16 bf16] at a
-// 208-B pitch, two images.  Per chunk 18 (k-group, input offset, class) steps of 6 NT MFMAs:
-// offset (0,0) feeds classes {0,1,2,3}, (0,1) {1,3}, (1,0) {2,3}, (1,1) {3}; one activation
-// fragment set per offset, one weight fragment set per step (ring, two steps ahead, running on
-// across chunks).  Staging and the operand split ride in the MFMA stream exactly as above.
-// ----------------------------------------------------------------------------
-struct DcPair { int o, c; };
-__host__ __device__ constexpr DcPair dc_pair(int j) {
-  constexpr int o_of[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
-  constexpr int c_of[9] = {0, 1, 2, 3, 1, 3, 2, 3, 3};
-  return DcPair{o_of[j], c_of[j]};
-}
-__host__ __device__ constexpr int dc_tap9(int j) {           // ky * 3 + kx of pair j
-  const DcPair q = dc_pair(j);
-  const int py = q.c >> 1, px = q.c & 1, iy = q.o >> 1, ix = q.o & 1;
-  const int ky = py ? (iy ? 0 : 2) : 1, kx = px ? (ix ? 0 : 2) : 1;
-  return ky * 3 + kx;
-}
-
-template <int NT>
-__global__ __launch_bounds__(NTHREADS, 1) void deconv_bf16x3_kernel(ConvParams p) {
-  constexpr int TY = 4, IY = TY + 1, IX = 33, CK = 32;
-  constexpr int NVOX = IY * IX;                 // 165
-  constexpr int NE = NVOX * 8;                  // 1320 staged 16-B fp32 quads per chunk
-  constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;   // 6
-  constexpr int PITCH = 208;                    // 2 k-groups x 3 planes x 32 B + 16 pad
-  constexpr int IMG = NPF * 32 * PITCH;         // 39,936 B
-  constexpr int NSTEP = 18;
-  constexpr int AHEAD = 3;
-  constexpr int CONV0 = NSTEP - 2 * NPF;        // 6
-  constexpr unsigned OOBV = 0x80000000u;
-  constexpr int COUT = 32 * NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int nck = p.Cin / CK;
-
-  int step, end;
-  int t = first_tile(p.ntiles, step, end);
-  if (t >= end) return;
-
-  f32x4 pf[NPF];
-  unsigned goff[NPF], yx[NPF], voff[NPF];
-#pragma unroll
-  for (int k = 0; k < NPF; ++k) {
-    const int e = tid + k * NTHREADS;
-    const int v = e >> 3, q8 = e & 7;
-    const int yy = v / IX, xx = v % IX;
-    goff[k] = 4u * (unsigned)((yy * p.Wi + xx) * p.Cin + 4 * q8);
-    yx[k] = e < NE ? ((unsigned)yy << 16 | (unsigned)xx) : 0x7fff0000u;
-  }
-  const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.wbytes);
-  const unsigned plane_bytes = 4u * (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)p.Cin;
-
-  struct Pos { int t, pz, iz, ck, yb, xb, m, b; unsigned base; };
-  auto item_pos = [&](int id) {
-    Pos q; q.t = id; q.pz = id & 1; q.iz = 0; q.ck = 0;
-    id >>= 1;
-    q.xb = (id % p.ntx) * 32; id /= p.ntx;
-    q.yb = (id % p.nty) * TY; id /= p.nty;
-    q.m = id % p.Di; q.b = id / p.Di;
-    q.base = (unsigned)(4l * (((((long)q.b * p.Di + q.m) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
-    return q;
-  };
-  auto advance = [&](Pos q) {                   // ck fastest, then the z-tap plane, then the item
-    if (++q.ck == nck) { q.ck = 0; if (++q.iz > q.pz) q = item_pos(q.t + step); }
-    return q;
-  };
-  auto item_offsets = [&](const Pos& q) {
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-      const int y = q.yb + (int)(yx[k] >> 16), x = q.xb + (int)(yx[k] & 0xffffu);
-      voff[k] = (y < p.Hi && x < p.Wi) ? q.base + goff[k] : OOBV;
-    }
-  };
-  auto chunk_rsrc = [&](const Pos& q) {
-    const bool live = q.t < end && q.m + q.iz < p.Di;
-    const long off = (long)q.iz * (long)plane_bytes + (long)q.ck * (CK * 4);
-    return make_rsrc(reinterpret_cast<const char*>(p.x) + off, live ? p.xbytes : 0u);
-  };
-  // weights [Cin/16][tap 27][n][plane][lane][16 B]; z-tap of this chunk: pz = 0 -> kz 1; pz = 1 -> kz 2, then 0
-  auto wbase_of = [&](const Pos& q) {
-    const int kz = q.pz ? (q.iz ? 0 : 2) : 1;
-    return (unsigned)((2 * q.ck * 27 + kz * 9) * NT) * (3 * 64 * 16);
-  };
-  const int wr_off = (tid >> 3) * PITCH + ((tid & 7) >> 2) * 96 + (tid & 3) * 8;
-  const int rd_off = (wave * IX + r) * PITCH + h * 16;
-
-  f32x16 acc[4][NT];
-  const unsigned lane16 = lane * 16u;
-  bf16x8 wq[AHEAD][NT][3];
-  unsigned half_a[3];
-  auto convert = [&](auto kc, auto hc, unsigned char* img) {
-    constexpr int k = decltype(kc)::value, half = decltype(hc)::value;
-    float r0 = half ? pf[k].z : pf[k].x, r1 = half ? pf[k].w : pf[k].y;
-    unsigned pl[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      pl[q] = pack_bf16(r0, r1);
-      if (q < 2) { r0 -= bf16_lo(pl[q]); r1 -= bf16_hi(pl[q]); }
-    }
-    if constexpr (half == 0) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) half_a[q] = pl[q];
-    } else {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        u32x2 v; v.x = half_a[q]; v.y = pl[q];
-        *reinterpret_cast<u32x2*>(img + wr_off + k * (32 * PITCH) + q * 32) = v;
-      }
-    }
-  };
-  // step s = g * 9 + j: k-group g, pair j
-  auto wload = [&](auto sc, unsigned wb) {
-    constexpr int s = decltype(sc)::value;
-    constexpr int g = s / 9, tap9 = dc_tap9(s % 9);
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        wq[s % AHEAD][n][q] = __builtin_bit_cast(
-            bf16x8, buffer_load16(wrsrc, lane16, wb + (((g * 27 + tap9) * NT + n) * 3 + q) * (64 * 16)));
-  };
-
-  Pos cur_pos = item_pos(t);
-  item_offsets(cur_pos);
-  {
-    const __amdgpu_buffer_rsrc_t rs0 = chunk_rsrc(cur_pos);
-    static_for<0, NPF>([&](auto kc) {
-      pf[decltype(kc)::value] = buffer_load16(rs0, voff[decltype(kc)::value], 0);
-    });
-    const unsigned w0 = wbase_of(cur_pos);
-    static_for<0, AHEAD - 1>([&](auto sc) { wload(sc, w0); });
-    static_for<0, NPF>([&](auto kc) {
-      convert(kc, std::integral_constant<int, 0>{}, lds_raw);
-      convert(kc, std::integral_constant<int, 1>{}, lds_raw);
-    });
-  }
-  int cur = 0;
-  while (true) {
-    __syncthreads();
-    const unsigned char* const rd = lds_raw + cur * IMG + rd_off;
-    unsigned char* const nimg = lds_raw + (cur ^ 1) * IMG;
-    const Pos nxt = advance(cur_pos);
-    if (nxt.iz == 0 && nxt.ck == 0) item_offsets(nxt);
-    const __amdgpu_buffer_rsrc_t nrsrc = chunk_rsrc(nxt);
-    if (cur_pos.iz == 0 && cur_pos.ck == 0) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[c][n][i] = 0.f;
-    }
-    const unsigned wchunk = wbase_of(cur_pos), wnext = nxt.t < end ? wbase_of(nxt) : 0u;
-    bf16x8 xq[2][3];
-    // activation fragment set xi = g * 4 + o (k-group, input offset)
-    auto xload = [&](auto xc) {
-      constexpr int xi = decltype(xc)::value;
-      constexpr int g = xi / 4, o = xi % 4, iy = o >> 1, ix = o & 1;
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        xq[xi & 1][q] = *reinterpret_cast<const bf16x8*>(rd + (iy * IX + ix) * PITCH + (g * 3 + q) * 32);
-    };
-    xload(std::integral_constant<int, 0>{});
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<0, NSTEP>([&](auto sc) {
-      constexpr int s = decltype(sc)::value;
-      constexpr int g = s / 9, j = s % 9;
-      constexpr DcPair pr = dc_pair(j);
-      constexpr int xi = g * 4 + pr.o;
-      constexpr bool fresh = (j == 0 || j == 4 || j == 6 || j == 8);
-      if constexpr (s + AHEAD - 1 < NSTEP) wload(std::integral_constant<int, s + AHEAD - 1>{}, wchunk);
-      else wload(std::integral_constant<int, s + AHEAD - 1 - NSTEP>{}, wnext);
-      if constexpr (fresh && xi + 1 < 8) xload(std::integral_constant<int, xi + 1>{});
-      if constexpr (s < NPF) pf[s] = buffer_load16(nrsrc, voff[s], 0);
-      __builtin_amdgcn_sched_barrier(0);
-      const bf16x8 xh = xq[xi & 1][0], xm = xq[xi & 1][1], xl = xq[xi & 1][2];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const bf16x8 wh = wq[s % AHEAD][n][0], wm = wq[s % AHEAD][n][1], wl = wq[s % AHEAD][n][2];
-        f32x16& a = acc[pr.c][n];
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, a, 0, 0, 0);
-      }
-      if constexpr (s >= CONV0)
-        convert(std::integral_constant<int, (s - CONV0) / 2>{},
-                std::integral_constant<int, (s - CONV0) % 2>{}, nimg);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    if (cur_pos.iz == cur_pos.pz && cur_pos.ck == nck - 1) {   // epilogue of the item
-      const int zo = 2 * cur_pos.m + cur_pos.pz;
-      const int ym = cur_pos.yb + wave, xm_ = cur_pos.xb + r;  // this lane's input-grid position
-      if (zo < p.Do && ym < p.Hi && xm_ < p.Wi) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const int cbase = n * 32 + 4 * h;
-          const Affine af = load_affine(p.scale, p.shift, cbase);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int yo = 2 * ym + (c >> 1), xo = 2 * xm_ + (c & 1);
-            if (yo >= p.Ho || xo >= p.Wo) continue;
-            const long vox = (((long)cur_pos.b * p.Do + zo) * p.Ho + yo) * p.Wo + xo;
-            const long rvox = (((long)cur_pos.b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo;
-            store_tile<COUT>(acc[c][n], af, p.relu, p.y + vox * COUT + cbase,
-                             p.res ? p.res + rvox * COUT + cbase : nullptr);
-          }
-        }
-      }
-    }
-    cur_pos = nxt; cur ^= 1;
-    if (cur_pos.t >= end) break;
-  }
-}
-
-// weights -> section 2 of the packed buffer: [Cin/16][tap][Cout/32][plane][lane][8 bf16],
-// tap = dz * 9 + t9 (ntaps = 27) or t9 (ntaps = 9)
-__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                           int Cin, int Cout, int transposed, int ntaps, int cin_src) {
-  const long n = (long)Cin * Cout * ntaps;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
-  const int NT = Cout / 32;
-  long i = idx;
-  const int j = i & 7; i >>= 3;
-  const int lane = i & 63; i >>= 6;
-  const int n_ = i % NT; i /= NT;
-  const int tap = i % ntaps; const int c16 = i / ntaps;
-  const int cin = 16 * c16 + 8 * (lane >> 5) + j, cout = 32 * n_ + (lane & 31);
-  const long src = transposed ? (((long)cin * Cout + cout) * ntaps + tap)
-                              : (((long)cout * cin_src + cin) * ntaps + tap);
-  float v = cin < cin_src ? w[src] : 0.f;
-  unsigned short* o = out + (((((long)c16 * ntaps + tap) * NT + n_) * 3) * 64 + lane) * 8 + j;
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const unsigned u = pack_bf16(v, 0.f);
-    o[(long)q * 64 * 8] = (unsigned short)(u & 0xffffu);
-    v -= bf16_lo(u);
-  }
-}
+#include "conv_bf16x3.hpp"   // conv_bf16x3_kernel, deconv_bf16x3_kernel, pack_weights_bf16x3_kernel
 
 // ----------------------------------------------------------------------------
 // ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1), Cout = 32*NT.
