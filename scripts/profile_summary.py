@@ -10,7 +10,7 @@ tag, stats_csv, bench_json, prof_json = sys.argv[1:5]
 bench = json.load(open(bench_json))
 prof = json.load(open(prof_json))
 rows = list(csv.DictReader(open(stats_csv)))
-OURS = ("conv3d_mfma", "conv_bf16x3", "deconv3d", "cout1", "soft_argmin", "volume_", "pack_weights", "spp_", "corr1d", "warp_")
+OURS = ("conv3d_mfma", "conv_bf16x3", "deconv_bf16x3", "deconv3d", "cout1", "soft_argmin", "volume_", "pack_weights", "spp_", "corr1d", "warp_")
 
 
 def short(n):
@@ -30,6 +30,9 @@ def plan_name(n):
         NT, TM, KZ, DIL = map(int, m.groups())
         return ("conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>" % (NT, TM) if KZ == 3 else
                 "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>" % (NT, TM, DIL))
+    m = re.match(r"deconv_bf16x3_kernel<(\d+)>", n)
+    if m:
+        return "deconv3d_bf16x3_mfma_kernel<NT=%s>" % m.group(1)
     m = re.match(r"deconv3d_mfma_kernel<(\d+), (\d+)>", n)
     if m:
         return "deconv3d_mfma_kernel<NT=%s,CK=%s>" % m.groups()
