@@ -99,7 +99,7 @@ def test_psmnet_trunk_training_step_vs_oracle(hip_lib):
     an activation within rounding distance of zero can take the other side in the two
     implementations, and one flipped unit in a BatchNorm layer that sees 80 voxels per channel
     moves that layer's gradients by ~1 %.  That happens for about one seed in three, with the
-    fp32-input MFMA as with the bf16x3 kernels (scripts/grad_check.py: seeds 71/81/91/101).  So:
+    fp32-input MFMA as with the bf16x3 kernels (tests/tools/grad_check.py: seeds 71/81/91/101).  So:
     every seed must stay within the bound a few flips can explain, and at least one must be
     flip-free, where all gradients agree to 2e-3 (measured: 3e-6).  A wrong backward kernel fails
     both."""
