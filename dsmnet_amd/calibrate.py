@@ -3,7 +3,7 @@
 The reference ships no weights (the README links are offline); benchmarks therefore use
 the reference's random initialisation (models/psmnet/stackhourglass.py:100-112).  Raw, it
 is numerically degenerate -- BatchNorm running statistics at (0, 1) blow activations up to
-~1e7 and the soft-argmin logits to std ~3e3 (scripts/diag_psmnet_error.py)
+~1e7 and the soft-argmin logits to std ~3e3 (tests/tools/diag_psmnet_error.py)
 -- so, as the goldens do, one train-mode pass populates the BN statistics and the last
 (linear) classifier layers are scaled to trained-network logit magnitudes.  Neither step
 changes the work per forward pass.

@@ -464,7 +464,7 @@ def calibrate_heads(name, sd, imL, imR, maxdisp=192, target_std=2.0):
     network has (std ~ 2).  With the reference's raw init the PSMNet cost has std ~ 2.8e3
     (max 1.3e4): the softmax is one-hot, fp32 rounding (1e-2 absolute on such costs)
     flips near-ties, and the reference's own fp32 result is 0.17-0.27 px away from an fp64
-    run of itself (scripts/diag_psmnet_error.py) -- no independent fp32 implementation can
+    run of itself (tests/tools/diag_psmnet_error.py) -- no independent fp32 implementation can
     match it to 1e-3 there.  The costs are linear in the scaled weights, so one factor
     suffices.  Returns the factor (stored in the golden fixture)."""
     factor = target_std / head_logit_std(name, sd, imL, imR, maxdisp)
