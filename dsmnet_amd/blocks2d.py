@@ -3,9 +3,10 @@ reference's child indices (``convbn`` -- models/psmnet/submodule.py:10-13), run 
 on the GPU as ONE launch of the MFMA convolution kernel with folded BN, fused ReLU and skip
 add, on NHWC (``torch.channels_last``) maps.
 
-Training mode, CPU tensors, and layer shapes the kernel does not cover (e.g. the SPP branches'
-1x1 convolution with padding 1) run the stock torch modules: the towers are outside the
-cost-volume hot path, so stock layers are legitimate there (autograd included).
+Training mode, CPU tensors, and layer shapes the kernels do not cover run the stock torch
+modules (autograd included); the SPP branches' 1x1 convolution with padding 1 has its own kernels
+(csrc/spp.hip, ``costvolume.spp_head``).  Stride-1 3x3 layers compute on the bf16 pipe (bf16x3,
+DESIGN.md 3.2a), stride-2 and 1x1 layers on the fp32-input MFMA.
 """
 import torch
 import torch.nn as nn

@@ -3,9 +3,9 @@
 
   convbn_3d            -> blocks3d.ConvBN3d (same children: '0' Conv3d, '1' BatchNorm3d)
   disparityregression  -> HIP expectation over the disparity axis (submodule.py:56-63)
-  convbn / BasicBlock / feature_extraction -- the 2-D tower, out of the hot path
-      ("stock 2-D layers, use torch as is"); same module tree so
-      reference checkpoints load.
+  convbn / BasicBlock / feature_extraction -- the 2-D tower: same
+      module tree so reference checkpoints load; in eval mode every convolution runs on the
+      MFMA kernels (blocks2d) and the SPP head on csrc/spp.hip; training takes stock layers.
 """
 import torch
 import torch.nn as nn
