@@ -41,6 +41,10 @@ class losses(torch.nn.Module):
         self.count_levels = count_levels
         self.weight_levels = [0] * count_levels
         self.weight_levels[-1] = 1
+        # capturable = True: no host-side test for "no valid pixel" (a device synchronisation);
+        # the loss is then a zero tensor instead of the reference's integer 0 -- what a hipGraph
+        # capture of the whole step needs (graphs.GraphedTrainStep sets it)
+        self.capturable = False
 
     def Weight_Adjust_levels(self, epoch):
         """Coarse-to-fine: the unit weight slides from the coarsest output (epoch 0) to the
@@ -59,6 +63,14 @@ class losses(torch.nn.Module):
 
     def loss_supervised(self, disp_gt, disp, flag_smooth=False, factor=1.0):
         mask = disp_gt > 0
+        if self.capturable:                     # same value, fixed shapes, no synchronisation
+            m = mask.to(disp.dtype)
+            n = m.sum().clamp_min(1.0)
+            loss = (torch.abs(disp_gt - disp) * m).sum() / n
+            if flag_smooth:
+                dxdy = (torch.abs(_diff1_dx(disp)) + torch.abs(_diff1_dy(disp))) / factor
+                loss = loss + 0.1 * (dxdy.clamp(0, 1) * m).sum() / n
+            return loss
         if not bool(mask.any()):
             return 0
         loss = torch.abs(disp_gt - disp)[mask].mean()

@@ -52,5 +52,26 @@ for k, v in sorted(timer.summary().items(), key=lambda kv: -kv[1]["ms"]):
     rate = v["work"] / (v["ms"] * 1e-3)
     print("   %-48s x%-4d %8.1f us avg %8.2f ms/step %8.2f %s" % (
         k, n // N, v["ms"] / n * 1e3, v["ms"] / N, rate / 1e12, "TFLOP/s" if ("mfma" in k or "wgrad" in k) else "TB/s"))
+# the same step replayed from a hipGraph (dsmnet_amd/graphs.py).  The eager steps above ran on
+# the default stream: drop every reference to their autograd graphs first (a stale
+# AccumulateGrad node tied to another stream invalidates the capture).
+import gc
+final_loss = loss.item()
+del loss
+opt.zero_grad(set_to_none=True)
+gc.collect()
+from dsmnet_amd import train
+from dsmnet_amd.graphs import GraphedTrainStep
+batch = torch.cat([left, right, target.unsqueeze(1)], 1)
+lossfun = train.losses("supervised", 1, 0)
+lossfun.Weight_Adjust_levels(0)
+gopt = torch.optim.Adam(m.parameters(), lr=1e-4, capturable=True)
+gstep = GraphedTrainStep(m, gopt, lossfun, batch)
+gstep(batch); torch.cuda.synchronize()
+a.record()
+for _ in range(N):
+    gstep(batch)
+b.record(); torch.cuda.synchronize()
+print("   hipGraph replay of the whole step (supervised pyramid loss, Adam): %.1f ms/step" % (a.elapsed_time(b) / N))
 print("   HIP kernels %.1f ms/step, everything else (stock torch: towers, BN, ReLU, adds, optimizer) %.1f ms/step"
       % (tot, ms - tot))

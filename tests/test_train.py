@@ -95,3 +95,13 @@ def test_average_meter():
     m.update(2.0, 2)
     m.update(5.0, 1)
     assert m.val == 5.0 and m.count == 3 and abs(m.avg - 3.0) < 1e-12
+
+
+def test_capturable_loss_equals_reference_form(gold):
+    lf, lc = T.losses("supervised", 1, 0), T.losses("supervised", 1, 0)
+    lc.capturable = True
+    for c in gold.meta["train_cases"]:
+        gt, pred = _case(c)
+        a, b = lf.loss_supervised(gt, pred, c["smooth"]), lc.loss_supervised(gt, pred, c["smooth"])
+        assert abs(float(a) - float(b)) <= 2e-6 * max(1.0, float(a))
+        assert torch.is_tensor(b)                      # a zero tensor where the reference returns int 0

@@ -64,3 +64,37 @@ def test_psmnet_train_step_and_lr_schedule(hip_lib):
     before = [p.detach().clone() for p in model.parameters()][:3]
     assert train.train_step(model, opt, lossfun, empty)[0] == 0.0
     assert all(torch.equal(a, b) for a, b in zip(before, list(model.parameters())[:3]))
+
+
+def test_graphed_train_step_follows_the_eager_trajectory(hip_lib):
+    """hipGraph replay of a whole PSMNet training step: same losses as eager steps from the same
+    initial state (float atomics in two backward kernels: agreement to 1e-3, not bit-exact)."""
+    import copy
+    from dsmnet_amd import train
+    from dsmnet_amd.graphs import GraphedTrainStep
+    from dsmnet_amd.models import model_create_by_name
+    torch.manual_seed(0)
+    m1 = model_create_by_name("psmnet", 192).cuda()
+    for i in (1, 2, 3):
+        getattr(m1, "classif%d" % i)[2].weight.data.mul_(1e-3)
+    m2 = copy.deepcopy(m1)
+    batches = [_batch(1, 256, 512, 6, s) for s in (5, 6, 7)]
+    lf1, lf2 = train.losses("supervised", 1, 0), train.losses("supervised", 1, 0)
+    lf1.Weight_Adjust_levels(0); lf2.Weight_Adjust_levels(0)
+    o1 = torch.optim.Adam(m1.parameters(), lr=1e-4)
+    eager = [train.train_step(m1, o1, lf1, b)[0] for b in batches + batches]
+    o2 = torch.optim.Adam(m2.parameters(), lr=1e-4, capturable=True)
+    state = copy.deepcopy(m2.state_dict())
+    step = GraphedTrainStep(m2, o2, lf2, batches[0], warmup=2)
+    # the warm-up and the capture ran real steps: rewind model and optimizer, then replay
+    m2.load_state_dict(state)
+    for st in o2.state.values():              # in place: the graph holds these very tensors
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+    graphed = [float(step(b)[0]) for b in batches + batches]
+    for a, b in zip(eager, graphed):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (eager, graphed)
+    assert graphed[-1] < graphed[0]
+    with pytest.raises(ValueError):
+        GraphedTrainStep(m2, torch.optim.Adam(m2.parameters(), lr=1e-4), lf2, batches[0])
