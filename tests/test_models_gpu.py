@@ -187,3 +187,25 @@ def test_graphed_forward_equals_eager(hip_lib):
         g(a[:, :, :128], b[:, :, :128])
     with pytest.raises(ValueError):
         GraphedForward(m.train(), a, b)
+
+
+@pytest.mark.parametrize("net,size,tol", [("gcnet", (64, 128), 0.0), ("dispnetcorr", (256, 512), 1e-4),
+                                         ("iresnet", (256, 512), 5e-3)])
+def test_graphed_forward_other_models(hip_lib, net, size, tol):
+    """The other three networks replay from a hipGraph too.  iResNet's warp draws a random
+    epsilon per call in eager mode (utils/imwrap.py:70); a captured forward keeps the one drawn
+    at capture time, hence its tolerance; DispNetC's stock MIOpen layers are not bit-reproducible
+    between a captured and an eager run (GCNet, all HIP kernels of this library, is)."""
+    from dsmnet_amd.graphs import GraphedForward
+    from dsmnet_amd.models import model_create_by_name
+    torch.manual_seed(0)
+    m = model_create_by_name(net, 192).cuda().eval()
+    a, b = torch.rand(1, 3, *size, device="cuda"), torch.rand(1, 3, *size, device="cuda")
+    g = GraphedForward(m, a, b)
+    with torch.no_grad():
+        want = m(a, b)[1]
+    got = g(a, b)[1]
+    assert len(got) == len(want)
+    for w, x in zip(want, got):
+        assert w.shape == x.shape
+        assert (w - x).abs().max().item() <= tol * max(1.0, w.abs().max().item())
