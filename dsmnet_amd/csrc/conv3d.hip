@@ -998,16 +998,17 @@ int run_conv(ConvParams p, hipStream_t s, int nsplit = 1) {
   return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK, KZ, KXY, DIL>, p, lds, s, 512 / nsplit, nsplit);
 }
 
-template <int NT, int TM, int KZ, int DIL>
+template <int NT, int TM, int KZ, int DIL, int S = 1>
 int run_conv_bf16x3(ConvParams p, hipStream_t s) {
-  constexpr int TY = 4 * TM, IY = TY + 2 * DIL, IX = 32 + 2 * DIL;
+  constexpr int TY = 4 * TM, IY = (TY - 1) * S + 2 * DIL + 1, IX = 31 * S + 2 * DIL + 1;
   constexpr int NPF = (IY * IX * 4 + NTHREADS - 1) / NTHREADS;
   p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, TY);
   const long nt = (long)p.B * p.Do * p.nty * p.ntx;
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
-  const size_t lds = (size_t)2 * NPF * 64 * 112;                     // two images, one workgroup per CU
-  return launch_tiles(conv_bf16x3_kernel<NT, TM, KZ, DIL>, p, lds, s, 256);
+  // two images, one workgroup per CU
+  const size_t lds = (S == 1) ? (size_t)2 * NPF * 64 * 112 : (size_t)2 * (IY * 66 + 4) * 112;
+  return launch_tiles(conv_bf16x3_kernel<NT, TM, KZ, DIL, S>, p, lds, s, 256);
 }
 
 template <int NT>
@@ -1164,6 +1165,11 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
     *pl = Plan{5, 1, NT, TM, 16, kd, 3, dil};
     return DSM_OK;
   }
+  if (a->stride == 2 && kd == 3 && NT == 2 && bf16x3_enabled() &&
+      4l * a->B * a->Di * a->Hi * a->Wi * a->Cin < 0x80000000l) {
+    *pl = Plan{5, 2, 2, 1, 16, 3, 3, 1};           // stride 2 on the bf16 pipe: 4-row tiles, Cout = 64
+    return DSM_OK;
+  }
   if (kd == 1) {                                   // 2-D towers: one staged slice, 16-channel chunks
     const int TM = (big && NT == 1 && a->stride == 1 && k == 3 && dil == 1) ? 2 : 1;
     *pl = Plan{0, a->stride, NT, TM, 16, 1, k, dil};
@@ -1200,7 +1206,8 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
     case 2: snprintf(buf, len, "conv3d_cout1_kernel<CK=%d>", pl.CK); break;
     case 4: snprintf(buf, len, "conv3d_cout1_zslide_kernel"); break;
     case 5:
-      if (pl.KZ == 3) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>", pl.NT, pl.TM);
+      if (pl.KZ == 3 && pl.S == 2) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<S=2,NT=%d,TM=%d>", pl.NT, pl.TM);
+      else if (pl.KZ == 3) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>", pl.NT, pl.TM);
       else snprintf(buf, len, "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>", pl.NT, pl.TM, pl.DIL);
       break;
     case 6: snprintf(buf, len, "deconv3d_bf16x3_mfma_kernel<NT=%d>", pl.NT); break;
@@ -1245,6 +1252,7 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   if (pl.kind == 5) {
     p.w = (const float*)a->w_packed + (size_t)a->Cin * a->Cout * pl.KZ * 9;   // section 2
     p.wbytes = (unsigned)bf16x3_section_bytes(a->Cin, a->Cout, pl.KZ, 3);
+    if (pl.S == 2) return run_conv_bf16x3<2, 1, 3, 1, 2>(p, s);
 #define DSM_CASE_BF(NT_, TM_, KZ_, DIL_) \
     if (pl.NT == NT_ && pl.TM == TM_ && pl.KZ == KZ_ && pl.DIL == DIL_) \
       return run_conv_bf16x3<NT_, TM_, KZ_, DIL_>(p, s)

@@ -59,19 +59,30 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2 (&pl)[3]) {
 
 // NT = Cout / 32; TM = 32x32 accumulator rows per wave (tile height 4 TM); KZ = 3: 3x3x3 on
 // volumes, KZ = 1: 3x3 on (B,1,H,W,C) views of NHWC maps; DIL: dilation in (y, x).
-template <int NT, int TM, int KZ, int DIL>
+// S = 2 (stride 2, DIL = 1, KZ = 3): the halo box is (2 TY + 1) x 65 voxels; its LDS image keeps
+// even and odd columns of a row apart (row pitch 66 voxels: 33 even, 33 odd) so that the lanes of
+// a fragment read, which step two input columns, stay 112 B apart.
+template <int NT, int TM, int KZ, int DIL, int S = 1>
 __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) {
-  constexpr int TY = 4 * TM, IY = TY + 2 * DIL, IX = 32 + 2 * DIL, NQ = 4, CK = 16;
+  static_assert(S == 1 || (S == 2 && DIL == 1 && KZ == 3), "stride 2: 3x3x3, no dilation");
+  constexpr int TY = 4 * TM, NQ = 4, CK = 16;
+  constexpr int IY = (TY - 1) * S + 2 * DIL + 1, IX = 31 * S + 2 * DIL + 1;
   constexpr int NVOX = IY * IX;
   constexpr int NE = NVOX * NQ;                 // staged 16-B fp32 quads per chunk
   constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
   constexpr int PITCH = 112;                    // bytes per voxel in LDS: 3 planes x 32 B + 16 pad
-  constexpr int IMG = NPF * 64 * PITCH;         // the tail quads land in padding
+  constexpr int RP = (S == 1) ? IX : 66;        // voxels per image row
+  constexpr int IMG = (S == 1) ? NPF * 64 * PITCH : (IY * RP + 4) * PITCH;   // (S = 1: the tail quads land in padding)
   constexpr int NITEM = 9;
   constexpr int NGROUP = NITEM * TM;            // (tap, row) groups of 6 NT MFMAs per chunk
   constexpr int AHEAD = 3;                      // weight ring: two items ahead (eight measured the same, twice)
-  constexpr int CONV0 = NGROUP - 2 * NPF;       // first group that converts (the last one finishes the chunk)
-  static_assert(NPF <= NGROUP && CONV0 >= 2, "staging schedule");
+  // staging schedule.  S = 1: one load per group over the first NPF groups, half an element
+  // split per group over the last 2 NPF.  S = 2 (ten elements for nine groups): every load in
+  // group 0, four halves per group from group 4.
+  constexpr int LPG = (S == 1) ? 1 : NPF;                       // loads per group
+  constexpr int CONV0 = (S == 1) ? NGROUP - 2 * NPF : 4;        // first group that converts
+  constexpr int CPG = (2 * NPF + (NGROUP - CONV0) - 1) / (NGROUP - CONV0);   // halves per group
+  static_assert(NPF <= NGROUP * LPG && CONV0 >= 2, "staging schedule");
   constexpr int COUT = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
@@ -103,9 +114,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
   struct Pos { int t, dz, ck, yb, xb, z; unsigned base; };   // base: byte offset of the box origin in the tile's own z-plane (mod 2^32)
   auto tile_pos = [&](int id) {
     Pos q; q.t = id; q.dz = 0; q.ck = 0;
-    q.xb = (id % p.ntx) * 32 - DIL; id /= p.ntx;
-    q.yb = (id % p.nty) * TY - DIL; id /= p.nty;
-    q.z = id % p.Do; const int b = id / p.Do;
+    q.xb = (id % p.ntx) * 32 * S - DIL; id /= p.ntx;
+    q.yb = (id % p.nty) * TY * S - DIL; id /= p.nty;
+    q.z = (id % p.Do) * S; const int b = id / p.Do;          // input plane of the centre z-tap
     q.base = (unsigned)(4l * (((((long)b * p.Di + q.z) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
     return q;
   };
@@ -139,10 +150,22 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
   // weights: [ck][dz][tap9][n][plane][lane][16 B]
   auto wbase_of = [&](const Pos& q) { return (unsigned)((q.ck * KZ + q.dz) * 9) * (NT * 3 * 64 * 16); };
 
-  // LDS write address of this thread's quad k: voxel (tid >> 2) + 64 k, channels 4 (tid & 3)..
+  // LDS write address of this thread's quad k.  S = 1: voxel (tid >> 2) + 64 k, an immediate
+  // per k; S = 2: the even/odd row layout, one register per k.
   const int wr_off = (tid >> 2) * PITCH + (tid & 3) * 8;
-  // this lane's activation fragment: voxel (row TM wave + m + dy, column r + dx), half h
-  const int rd_off = ((wave * TM) * IX + r) * PITCH + h * 16;
+  int wofs[S == 1 ? 1 : NPF];
+  if constexpr (S == 2) {
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      const int e = min(tid + k * NTHREADS, NE - 1);
+      const int v = e / NQ, yy = v / IX, xx = v % IX;
+      wofs[k] = (tid + k * NTHREADS < NE)
+                    ? (yy * RP + (xx & 1) * 33 + (xx >> 1)) * PITCH + (e % NQ) * 8
+                    : (IY * RP) * PITCH + (tid & 3) * 8;       // the tail: spare voxels behind the image
+    }
+  }
+  // this lane's activation fragment: voxel (row (TM wave + m) S + dy, column r S + dx), half h
+  const int rd_off = ((wave * TM * S) * RP + r) * PITCH + h * 16;
 
   f32x16 acc[TM][NT];
   const unsigned lane16 = lane * 16u;
@@ -168,7 +191,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         u32x2 v; v.x = half_a[q]; v.y = pl[q];
-        *reinterpret_cast<u32x2*>(img + wr_off + k * (64 * PITCH) + q * 32) = v;
+        if constexpr (S == 1) *reinterpret_cast<u32x2*>(img + wr_off + k * (64 * PITCH) + q * 32) = v;
+        else *reinterpret_cast<u32x2*>(img + wofs[k] + q * 32) = v;
       }
     }
   };
@@ -219,9 +243,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
       constexpr int s = decltype(sc)::value;
       constexpr int item = s / TM, m = s % TM;
       constexpr int dy = (item / 3) * DIL, dx = (item % 3) * DIL;
+      constexpr int vo = (S == 1) ? (m + dy) * RP + dx : (m * 2 + dy) * RP + (dx & 1) * 33 + (dx >> 1);
 #pragma unroll
       for (int q = 0; q < 3; ++q)
-        xq[s & 1][q] = *reinterpret_cast<const bf16x8*>(rd + ((m + dy) * IX + dx) * PITCH + q * 32);
+        xq[s & 1][q] = *reinterpret_cast<const bf16x8*>(rd + vo * PITCH + q * 32);
     };
     DSM_STAMP(3);
     xload(std::integral_constant<int, 0>{});
@@ -238,9 +263,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
 #if !(defined(DSM_ABLATE) && DSM_ABLATE == 4)
         if constexpr (s + 1 < NGROUP) xload(std::integral_constant<int, s + 1>{});
 #endif
-        // staged loads of the next chunk: one per group over the first NPF groups
+        // staged loads of the next chunk
 #if !(defined(DSM_ABLATE) && DSM_ABLATE == 2)
-        if constexpr (s < NPF) pf[s] = buffer_load16(nrsrc, voff[s], 0);
+        static_for<0, LPG>([&](auto jc) {
+          constexpr int k = s * LPG + decltype(jc)::value;
+          if constexpr (k < NPF) pf[k] = buffer_load16(nrsrc, voff[k], 0);
+        });
 #endif
         __builtin_amdgcn_sched_barrier(0);
         const bf16x8 xh = xq[s & 1][0], xm = xq[s & 1][1], xl = xq[s & 1][2];
@@ -259,9 +287,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
         // split half an element of the next chunk into the other image, in this group's gaps:
         // element j was requested in group j and is converted in groups CONV0 + 2j, + 2j + 1
 #if !(defined(DSM_ABLATE) && DSM_ABLATE == 1)
-        if constexpr (s >= CONV0 && s < CONV0 + 2 * NPF)
-          convert(std::integral_constant<int, (s - CONV0) / 2>{},
-                  std::integral_constant<int, (s - CONV0) % 2>{}, nimg);
+        static_for<0, CPG>([&](auto jc) {
+          constexpr int hidx = (s - CONV0) * CPG + decltype(jc)::value;   // half-element index
+          if constexpr (s >= CONV0 && hidx < 2 * NPF)
+            convert(std::integral_constant<int, hidx / 2>{}, std::integral_constant<int, hidx % 2>{}, nimg);
+        });
 #endif
         __builtin_amdgcn_sched_barrier(0);
       });
