@@ -25,9 +25,11 @@ def plan_name(n):
         S, NT, TM, CK, KZ, K, DIL = map(int, m.groups())
         return ("conv3d_mfma_kernel<S=%d,NT=%d,TM=%d,CK=%d>" % (S, NT, TM, CK) if KZ == 3 else
                 "conv2d_mfma_kernel<S=%d,NT=%d,TM=%d,K=%d,DIL=%d>" % (S, NT, TM, K, DIL))
-    m = re.match(r"conv_bf16x3_kernel<(\d+), (\d+), (\d+), (\d+)>", n)
+    m = re.match(r"conv_bf16x3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", n)
     if m:
-        NT, TM, KZ, DIL = map(int, m.groups())
+        NT, TM, KZ, DIL, S = map(int, m.groups())
+        if S == 2:
+            return "conv3d_bf16x3_mfma_kernel<S=2,NT=%d,TM=%d>" % (NT, TM)
         return ("conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>" % (NT, TM) if KZ == 3 else
                 "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>" % (NT, TM, DIL))
     m = re.match(r"deconv_bf16x3_kernel<(\d+)>", n)
