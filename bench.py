@@ -252,6 +252,15 @@ def main():
             base, err = cpu_baseline(model, left, right, preds)
             result["cpu_baseline"] = base
             result["parity_max_abs_px_vs_cpu"] = err
+        mode = os.environ.get("DSM_CONV_PRECISION", "bf16x3")
+        result["precision"] = {
+            "storage_and_accumulate": "f32",
+            "conv_products": ("fp32-input MFMA" if mode.startswith("f") else
+                              "each fp32 operand split exactly into 3 bf16 terms; 6 bf16 MFMAs per product, "
+                              "dropped terms <= 3*2^-25 relative; fp32 accumulate"),
+            "conv_error_vs_float64": "max rel 0.8-1.3e-6, rms 4.1-5.9e-7 on 6 layer shapes; the fp32-input MFMA "
+                                     "kernels measure 0.8-1.5e-6 / 4.2-5.9e-7 (scripts/precision_check.py, DESIGN.md 3.2a)",
+            "gate": "forward disparity vs the fp32 CPU reference path <= 1e-3 px (parity_max_abs_px_vs_cpu)"}
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
