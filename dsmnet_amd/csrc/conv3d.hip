@@ -866,7 +866,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_zslide_kernel(
 // voxel quad is read once per thread and used for all the taps it feeds; weights are LDS
 // broadcasts.  (The first version -- one thread per output voxel gathering 1..8 voxels from
 // L2 with 128-B-strided lanes -- ran at 0.23 TB/s: 2.2 ms for GCNet's 100 MB output.)
-__global__ __launch_bounds__(NTHREADS) void deconv3d_cout1_kernel(ConvParams p) {
+__global__ __launch_bounds__(NTHREADS, 3) void deconv3d_cout1_kernel(ConvParams p) {
   constexpr int TY = 4, IZ = 2, IY = TY + 1, IX = 33, NQ = 8;
   constexpr int NE = IZ * IY * IX * NQ;                // 2640
   constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;  // 11
@@ -914,6 +914,9 @@ __global__ __launch_bounds__(NTHREADS) void deconv3d_cout1_kernel(ConvParams p) 
         }
         acc[c] = a;
       }
+      // one offset's eight quads live at a time: left alone, hipcc hoists every LDS read of the
+      // item to the top (256 VGPRs + AGPR spills, one wave per SIMD, 0.9 ms at GCNet's size)
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   const int ym = ty0 + ty, xm = tx0 + r;
