@@ -64,15 +64,19 @@ __global__ __launch_bounds__(128) void spp_branches_kernel(const float* __restri
                                                            int w8) {
   __shared__ float v[C_SKIP];
   __shared__ float part[4][C_BR];
-  const BranchGeo g = branch_geo(B, h8, w8);
-  long id = blockIdx.x;
-  int bi = 0;
-  while (bi < 3 && id >= (g.off[bi + 1] - g.off[bi]) / C_BR) { id -= (g.off[bi + 1] - g.off[bi]) / C_BR; ++bi; }
-  const int hb = g.h[bi], wb = g.w[bi], f = 1 << bi;
+  // branch bi: map (h8 >> bi) + 2 by (w8 >> bi) + 2, maps back to back (scalar walk: indexing the
+  // BranchGeo arrays with a runtime bi would put them in scratch)
+  long id = blockIdx.x, off = 0;
+  int bi = 0, hb = h8 + 2, wb = w8 + 2;
+  while (bi < 3 && id >= (long)B * hb * wb) {
+    id -= (long)B * hb * wb; off += (long)B * hb * wb * C_BR;
+    ++bi; hb = (h8 >> bi) + 2; wb = (w8 >> bi) + 2;
+  }
+  const int f = 1 << bi;
   const int xx = (int)(id % wb); id /= wb;
   const int yy = (int)(id % hb); const int b = (int)(id / hb);
   const int t = threadIdx.x;
-  float* o = out + g.off[bi] + (((long)b * hb + yy) * wb + xx) * C_BR;
+  float* o = out + off + (((long)b * hb + yy) * wb + xx) * C_BR;
   const bool border = yy == 0 || xx == 0 || yy == hb - 1 || xx == wb - 1;   // block-uniform
   if (border) {                                     // zero padding: conv = 0, BN(0) = shift
     if (t < C_BR) o[t] = fmaxf(shift[bi * C_BR + t], 0.f);
