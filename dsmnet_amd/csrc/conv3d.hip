@@ -1163,8 +1163,8 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
     static int force_tm = -1;                      // DSM_BF16X3_TM=2|4: tile-height A/B runs
     if (force_tm < 0) { const char* e = getenv("DSM_BF16X3_TM"); force_tm = e ? atoi(e) : 0; }
     const long tiles16 = (long)a->B * a->Do * dsm_cdiv(a->Ho, 16) * dsm_cdiv(a->Wo, 32);
-    int TM = (kd == 3 && NT == 1 && tiles16 >= 224) ? 4 : 2;
-    if (force_tm == 2 || (force_tm == 4 && kd == 3 && NT == 1)) TM = force_tm;
+    int TM = (NT == 1 && dil == 1 && tiles16 >= 224) ? 4 : 2;       // 3-D, and the 32-channel 2-D maps at 1/2 resolution
+    if (force_tm == 2 || (force_tm == 4 && NT == 1 && dil == 1)) TM = force_tm;
     *pl = Plan{5, 1, NT, TM, 16, kd, 3, dil};
     return DSM_OK;
   }
@@ -1260,7 +1260,8 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
     if (pl.NT == NT_ && pl.TM == TM_ && pl.KZ == KZ_ && pl.DIL == DIL_) \
       return run_conv_bf16x3<NT_, TM_, KZ_, DIL_>(p, s)
     DSM_CASE_BF(1, 4, 3, 1); DSM_CASE_BF(1, 2, 3, 1); DSM_CASE_BF(2, 2, 3, 1);
-    DSM_CASE_BF(1, 2, 1, 1); DSM_CASE_BF(2, 2, 1, 1); DSM_CASE_BF(4, 2, 1, 1); DSM_CASE_BF(4, 2, 1, 2);
+    DSM_CASE_BF(1, 4, 1, 1); DSM_CASE_BF(1, 2, 1, 1); DSM_CASE_BF(2, 2, 1, 1); DSM_CASE_BF(4, 2, 1, 1);
+    DSM_CASE_BF(4, 2, 1, 2);
 #undef DSM_CASE_BF
     return DSM_ERR_UNSUPPORTED;
   }
