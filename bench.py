@@ -153,13 +153,23 @@ def main():
                          "--nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # DSM_BENCH_REHEARSE=1: rehearsal of the N > 1 control path on a box with fewer GPUs than ranks
+    # (ranks share devices, gloo carries the barrier and the max-reduce).  Its value is not a
+    # measurement and the JSON line says so.
+    rehearse = os.environ.get("DSM_BENCH_REHEARSE") == "1"
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and not rehearse:
+        raise SystemExit("rank %d has no GPU of its own (%d visible)" % (local_rank, ndev))
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     from dsmnet_amd import calibrate, costvolume
     from dsmnet_amd.models import model_create_by_name
@@ -214,7 +224,7 @@ def main():
             instrumented = time.perf_counter() - t1
             costvolume.set_timer(None)
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -225,7 +235,8 @@ def main():
             "metric": METRIC, "value": round(world * args.steps / elapsed, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, not a measurement)" if rehearse else ""),
             "config": {"workload": "PSMNet stacked-hourglass forward, D=192, 384x1280, one pair "
                                    "per GPU per step (BASELINE configs[3]: batch 8 over 8 GPUs)",
                        "height": H, "width": W, "maxdisp": MAXDISP, "pairs_per_gpu_per_step": 1,
