@@ -1010,7 +1010,8 @@ int run_conv_bf16x3(ConvParams p, hipStream_t s) {
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
   // two images, one workgroup per CU
-  const size_t lds = (S == 1) ? (size_t)2 * NPF * 64 * 112 : (size_t)2 * (IY * 66 + 4) * 112;
+  const size_t lds = ((S == 1) ? (size_t)2 * NPF * 64 * 112 : (size_t)2 * (IY * 66 + 4) * 112) +
+                     2 * 32 * NT * sizeof(float);                    // + scale / shift
   return launch_tiles(conv_bf16x3_kernel<NT, TM, KZ, DIL, S>, p, lds, s, 256);
 }
 
@@ -1020,7 +1021,7 @@ int run_deconv_bf16x3(ConvParams p, hipStream_t s) {
   const long nt = (long)p.B * p.Di * p.nty * p.ntx * 2;       // x2: z-parity
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
-  const size_t lds = (size_t)2 * 6 * 32 * 208;                       // two images, 79.9 KB
+  const size_t lds = (size_t)2 * 6 * 32 * 208 + 2 * 32 * NT * sizeof(float);   // two images (79.9 KB) + scale / shift
   return launch_tiles(deconv_bf16x3_kernel<NT>, p, lds, s, 256);
 }
 

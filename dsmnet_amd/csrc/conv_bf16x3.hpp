@@ -57,6 +57,24 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2 (&pl)[3]) {
   }
 }
 
+// Folded-BN scale / shift of a launch, staged once into LDS behind the two images: the epilogue
+// reads them with LDS latency instead of an L2 round trip per tile (stamps: the epilogue was 15 %
+// of a 64-channel 2-D layer's in-loop time, most of it waiting for these 2 x COUT floats).
+__device__ __forceinline__ void stage_affine_lds(float* aff, const float* scale, const float* shift,
+                                                 int cout, int tid) {
+  for (int i = tid; i < 2 * cout; i += NTHREADS)
+    aff[i] = i < cout ? (scale ? scale[i] : 1.f) : (shift ? shift[i - cout] : 0.f);
+}
+__device__ __forceinline__ Affine load_affine_lds(const float* aff, int cout, int cbase) {
+  Affine a;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    a.sc[g] = *reinterpret_cast<const f32x4*>(aff + cbase + 8 * g);
+    a.sh[g] = *reinterpret_cast<const f32x4*>(aff + cout + cbase + 8 * g);
+  }
+  return a;
+}
+
 // NT = Cout / 32; TM = 32x32 accumulator rows per wave (tile height 4 TM); KZ = 3: 3x3x3 on
 // volumes, KZ = 1: 3x3 on (B,1,H,W,C) views of NHWC maps; DIL: dilation in (y, x).
 // S = 2 (stride 2, DIL = 1, KZ = 3): the halo box is (2 TY + 1) x 65 voxels; its LDS image keeps
@@ -206,6 +224,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
             bf16x8, buffer_load16(wrsrc, lane16, wb + ((item * NT + n) * 3 + q) * (64 * 16)));
   };
 
+  float* const aff = reinterpret_cast<float*>(lds_raw + 2 * IMG);
+  stage_affine_lds(aff, p.scale, p.shift, COUT, tid);        // visible after the loop's first barrier
   Pos cur_pos = tile_pos(t);
   tile_offsets(cur_pos);
   {                                             // first chunk of the launch: staged synchronously
@@ -310,7 +330,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int cbase = n * 32 + 4 * h;
-        const Affine af = load_affine(p.scale, p.shift, cbase);
+        const Affine af = load_affine_lds(aff, COUT, cbase);
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
           const int yo = ty0 + wave * TM + m;
@@ -458,6 +478,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void deconv_bf16x3_kernel(ConvParams p
             bf16x8, buffer_load16(wrsrc, lane16, wb + (((g * 27 + tap9) * NT + n) * 3 + q) * (64 * 16)));
   };
 
+  float* const aff = reinterpret_cast<float*>(lds_raw + 2 * IMG);
+  stage_affine_lds(aff, p.scale, p.shift, COUT, tid);
   Pos cur_pos = item_pos(t);
   item_offsets(cur_pos);
   {
@@ -535,7 +557,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void deconv_bf16x3_kernel(ConvParams p
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const int cbase = n * 32 + 4 * h;
-          const Affine af = load_affine(p.scale, p.shift, cbase);
+          const Affine af = load_affine_lds(aff, COUT, cbase);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const int yo = 2 * ym + (c >> 1), xo = 2 * xm_ + (c & 1);
