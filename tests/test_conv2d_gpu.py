@@ -16,7 +16,8 @@ def cv(hip_lib):
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,dil,shape", [
-    (32, 32, 3, 1, 1, (2, 24, 40)), (32, 32, 3, 1, 1, (1, 96, 160)),   # TM=1 and TM=2 tiles
+    (32, 32, 3, 1, 1, (2, 24, 40)), (32, 32, 3, 1, 1, (1, 96, 160)),   # 8-row tiles
+    (32, 32, 3, 1, 1, (2, 190, 630)),                                   # 16-row tiles (1/2-resolution maps), ragged
     (64, 64, 3, 1, 1, (2, 13, 37)), (128, 128, 3, 1, 1, (1, 9, 33)),
     (128, 128, 3, 1, 2, (2, 12, 40)),                                   # layer4: dilation 2
     (16, 32, 3, 2, 1, (2, 25, 70)), (32, 64, 3, 2, 1, (1, 24, 64)),     # stride 2
