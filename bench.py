@@ -3,24 +3,32 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by the driver as
+N > 1 runs one rank per GPU.  Under the driver's launcher
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-one rank per GPU.  Stereo pairs are independent, so the job shards them across ranks
-with no data-path collective (weak scaling: one pair per GPU per step); RCCL is used only
-for the timing barrier and the max-over-ranks reduction.
+the ranks come from RANK / LOCAL_RANK / WORLD_SIZE.  A plain `python bench.py --gpus N` (no
+WORLD_SIZE in the environment) starts the N rank processes itself -- child processes, started
+before the parent has made any GPU call -- waits for them and exits non-zero if any failed.
+Stereo pairs are independent, so the job shards them across ranks with no data-path
+collective (weak scaling: one pair per GPU per step); RCCL carries only the timing barrier
+and the max-over-ranks reduction.
 
 A step = one forward pass over one synthetic KITTI-shaped pair already resident in HBM
 (2-D towers -> cost volume -> 3-D trunk -> three soft-argmin heads, all three computed as
 the reference does).  Weights: the reference's random initialisation, BN statistics and
 head scale calibrated (dsmnet_amd/calibrate.py).  Compute dtype fp32, as the reference.
 
-Rank 0 prints ONE JSON line with the throughput, the per-kernel rooflines measured live
-with HIP events on the launch stream inside the timed region, and (N=1) the CPU baseline:
-the oracle restatement of the same forward on the same weights, timed on the host cores.
+Rank 0 prints ONE JSON line: throughput (K steps between two barriers), per-step spread
+(median / min from one HIP event per step), the per-kernel rooflines from a second,
+instrumented pass (two HIP events per launch on the launch stream) and, at N=1, the CPU
+baseline: the oracle restatement of the same forward on the same weights, per stage, timed on
+the host cores.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -41,24 +49,46 @@ BF16X3_MFMAS_PER_PRODUCT = 6
 
 
 def synthetic_pair(seed, device):
-    """torch.rand images, ImageNet-normalised (models/test_models_time.py:17-23,
-    myTransforms/__init__.py:8); the right view is the left one shifted by 7 px."""
+    """Two independent torch.rand images, ImageNet-normalised (SURVEY.md 8d;
+    models/test_models_time.py:17-23, myTransforms/__init__.py:8)."""
     g = torch.Generator().manual_seed(seed)
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
     left = torch.rand(1, 3, H, W, generator=g)
-    right = torch.roll(left, shifts=-7, dims=3)
+    right = torch.rand(1, 3, H, W, generator=g)
     return ((left - mean) / std).to(device), ((right - mean) / std).to(device)
+
+
+def stage_of(kernel):
+    """Forward stage a kernel of this library belongs to (per-stage timing)."""
+    if kernel.startswith(("conv2d", "spp_")):
+        return "towers"
+    if kernel.startswith("volume"):
+        return "volume"
+    if kernel.startswith(("soft_argmin", "conv3d_cout1")):
+        return "heads"
+    return "trunk"
+
+
+def load_traffic():
+    """profiles/traffic.json: HBM-side bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE
+    and WRITE_SIZE in separate passes, gfx950 corrections applied), keyed by the plan name of the
+    kernel, each entry with the pass and commit it was measured at."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return {}
+    with open(tpath) as fh:
+        doc = json.load(fh)
+    out = {}
+    for name, e in doc.get("kernels", {}).items():
+        out[name] = e
+    return out
 
 
 def kernel_rooflines(summary, steps):
     """Per kernel: algorithmic work per launch / average launch duration vs the roofline
     that bounds it.  HBM kernels count bytes, MFMA kernels count FLOPs."""
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as fh:
-            traffic = json.load(fh).get("hbm_bytes_per_launch", {})
+    traffic = load_traffic()
     out = {}
     for name, e in summary.items():
         n, ms, work = e["launches"], e["ms"], e["work"]
@@ -67,9 +97,9 @@ def kernel_rooflines(summary, steps):
         mfma = "mfma" in name
         extra = {}
         if mfma and "bf16x3" in name:
-            # fp32 operands split exactly into 3 bf16 terms, 6 of the 9 cross terms on
-            # v_mfma_f32_32x32x16_bf16, fp32 accumulate: `achieved` stays ALGORITHMIC fp32 FLOP/s,
-            # `peak` is the dense bf16 MFMA peak divided by the 6 MFMAs every product costs
+            # fp32 operands split exactly into 3 bf16 terms, 6 of the 9 cross terms on the bf16
+            # MFMA, fp32 accumulate: `achieved` stays ALGORITHMIC fp32 FLOP/s, `peak` is the
+            # dense bf16 MFMA peak divided by the 6 MFMAs every product costs
             achieved, unit, bound = per_launch / avg_s / 1e12, "TFLOP/s", "mfma"
             peak = round(PEAK_BF16_MFMA_TFLOPS / BF16X3_MFMAS_PER_PRODUCT, 1)
             extra = {"mfma_dtype": "bf16 (3-term split of fp32 operands, 6 MFMAs per product, fp32 accumulate)",
@@ -80,12 +110,15 @@ def kernel_rooflines(summary, steps):
             achieved, peak, unit, bound = per_launch / avg_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s", "mfma"
         else:
             achieved, peak, unit, bound = per_launch / avg_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+        tr = traffic.get(name)
         out[name] = {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                     "frac": round(achieved / peak, 4), "traffic": traffic.get(name),
+                     "frac": round(achieved / peak, 4),
+                     "traffic": None if tr is None else tr["bytes_per_launch"],
+                     "traffic_source": None if tr is None else tr["source"],
                      "frac_of_copy_ceiling": None if mfma else round(achieved / HBM_COPY_CEILING_GBS, 4),
                      "launches_per_step": n / steps, "avg_launch_us": round(avg_s * 1e6, 2),
                      "ms_per_step": round(ms / steps, 4),
-                     "work_per_launch": per_launch}
+                     "work_per_launch": per_launch, "stage": stage_of(name)}
         out[name].update(extra)
     return out
 
@@ -109,28 +142,99 @@ def host_cores():
 
 
 def cpu_baseline(model, left, right, gpu_preds):
-    """The oracle restatement of the same forward (same weights, same pair) on the host
-    cores.  Bounded sample: one untimed warm-up pass on a 256x512 crop, then whole
-    384x1280 passes until >= 10 s of timed work (at most 3)."""
+    """The oracle restatement of the same forward (same weights, same pair) on the host cores,
+    stage by stage (towers / volume / trunk / heads -- models/test_models_time.py:11-32 is the
+    reference's own timing script).  Bounded sample: one untimed warm-up pass on a 256x512
+    crop, then whole 384x1280 passes until >= 10 s of timed work (at most 3)."""
     from oracle import models as OM          # test infrastructure: baseline + checker only
+    from oracle import ops as OO
     torch.set_num_threads(host_cores())
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     l, r = left.cpu(), right.cpu()
+    net = OM.Net(sd)
+
+    def staged_forward():
+        t = [time.perf_counter()]
+        fl, fr = OM.psmnet_features(net, l), OM.psmnet_features(net, r)
+        t.append(time.perf_counter())
+        vol = OO.concat_volume(fl, fr, MAXDISP // 4, mask_left=True)
+        t.append(time.perf_counter())
+        c1, c2, c3 = OM.psmnet_trunk(net, vol)
+        del vol
+        t.append(time.perf_counter())
+        preds = [OO.soft_argmin(c, (MAXDISP, H, W)) for c in (c3, c2, c1)]
+        t.append(time.perf_counter())
+        stages = dict(zip(("towers", "volume", "trunk", "heads"),
+                          (b - a for a, b in zip(t[:-1], t[1:]))))
+        return preds, t[-1] - t[0], stages
+
     with torch.no_grad():
         OM.forward("psmnet", sd, l[..., :256, :512].contiguous(), r[..., :256, :512].contiguous())
-        times, preds = [], None
-        while sum(times) < 10.0 and len(times) < 3:
-            t0 = time.perf_counter()
-            preds = OM.forward("psmnet", sd, l, r, MAXDISP)
-            times.append(time.perf_counter() - t0)
+        runs, preds = [], None
+        while sum(x[0] for x in runs) < 10.0 and len(runs) < 3:
+            preds, total, stages = staged_forward()
+            runs.append((total, stages))
     err = max((a.cpu() - b).abs().max().item() for a, b in zip(gpu_preds, preds))
-    best = min(times)
+    times = [x[0] for x in runs]
+    best, best_stages = min(runs, key=lambda x: x[0])
     return {"value": round(1.0 / best, 5), "unit": "pairs/s", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": "%d whole forward pass(es) of the same 384x1280 pair, same weights "
-                      "(oracle/models.py psmnet on torch CPU fp32); best of %d; %.1f s timed"
-                      % (len(times), len(times), sum(times)),
-            "seconds_per_pair": round(best, 3)}, err
+                      "(oracle/models.py psmnet stages on torch CPU fp32); value = best of %d; "
+                      "%.1f s timed" % (len(times), len(times), sum(times)),
+            "seconds_per_pair": {"min": round(best, 3), "median": round(statistics.median(times), 3)},
+            "stage_seconds": {k: round(v, 3) for k, v in best_stages.items()}}, err
+
+
+# ----------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without a launcher around it
+# ----------------------------------------------------------------------------
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """Start n rank processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set) and
+    wait for them.  The parent makes no GPU call: the children are ordinary child processes
+    (never an exec of a process that has initialised the GPU).  Rank 0's stdout is the
+    parent's, so its JSON line is the line of this command.  Returns the exit code."""
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(_free_port()), "DSM_BENCH_SELF_LAUNCHED": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL on this host driver
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print("bench.py: rank %d exited with code %d; stopping the other ranks" % (r, code),
+                          file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        rc = 130
+    finally:
+        for p in procs:                      # exactly the processes started above
+            if p.poll() is None:
+                p.terminate()
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+    return rc
 
 
 def main():
@@ -145,18 +249,24 @@ def main():
                     help="skip the second, instrumented pass (per-launch HIP events -> rooflines)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs one rank per GPU: launch with torch.distributed.run "
-                         "--nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # DSM_BENCH_REHEARSE=1: rehearsal of the N > 1 control path on a box with fewer GPUs than ranks
     # (ranks share devices, gloo carries the barrier and the max-reduce).  Its value is not a
     # measurement and the JSON line says so.
     rehearse = os.environ.get("DSM_BENCH_REHEARSE") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one.  device_count() does not initialise the GPU.
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not rehearse:
+            raise SystemExit("--gpus %d: only %d GPU(s) visible" % (args.gpus, ndev))
+        sys.exit(launch_ranks(args.gpus))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     ndev = torch.cuda.device_count()
     if local_rank >= ndev and not rehearse:
         raise SystemExit("rank %d has no GPU of its own (%d visible)" % (local_rank, ndev))
@@ -202,17 +312,23 @@ def main():
                 print("bench.py: hipGraph capture failed (%s); timing eager launches" % e,
                       file=sys.stderr)
         preds = step()
-        # the timed region: K steps, nothing but the forward passes between the barriers
+        # the timed region: K steps between the barriers; one HIP event record per step on the
+        # launch stream (for the per-step spread) is the only other thing inside
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        marks[0].record()
+        for i in range(args.steps):
             preds = step()
+            marks[i + 1].record()
         barrier()
         elapsed = time.perf_counter() - t0
+        step_ms = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
         # the same K steps again with two HIP events around every launch of this library (on
         # the launch stream): per-kernel durations for the rooflines.  Kept out of the timed
-        # region because the event records themselves cost ~5 % of a step (0.7 ms of 13.4).
+        # region because the event records themselves cost ~5 % of a step.
         timer = instrumented = None
+        volume_b2b_us = None
         if not args.no_kernel_timing:
             timer = costvolume.LaunchTimer()
             costvolume.set_timer(timer)
@@ -223,6 +339,21 @@ def main():
             barrier()
             instrumented = time.perf_counter() - t1
             costvolume.set_timer(None)
+            # the cost-volume build launched back to back (each launch must first drain the
+            # previous one's dirty Infinity-Cache lines): the sustained-write rate, reported
+            # beside the in-forward one
+            fl, fr = model.features(left, right)
+            vols = [costvolume.concat_volume(fl, fr, MAXDISP // 4, True) for _ in range(2)]
+            del vols
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nrep = 20
+            e0.record()
+            for _ in range(nrep):
+                costvolume.concat_volume(fl, fr, MAXDISP // 4, True)
+            e1.record()
+            torch.cuda.synchronize()
+            volume_b2b_us = e0.elapsed_time(e1) / nrep * 1e3
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -241,18 +372,33 @@ def main():
                                    "per GPU per step (BASELINE configs[3]: batch 8 over 8 GPUs)",
                        "height": H, "width": W, "maxdisp": MAXDISP, "pairs_per_gpu_per_step": 1,
                        "heads": 3, "parallelism": "pairs sharded over ranks, no collective",
+                       "inputs": "left and right: independent torch.rand images, ImageNet-normalised",
                        "weights": "reference init (seed 0), BN + heads calibrated",
                        "launch": launch,
-                       "conv_precision": os.environ.get("DSM_CONV_PRECISION", "bf16x3") + " (3-D 32-channel "
-                                         "stride-1 layers; DSM_CONV_PRECISION=fp32 keeps the fp32-input MFMA)"},
+                       "launcher": ("self-launched child ranks" if os.environ.get("DSM_BENCH_SELF_LAUNCHED")
+                                    else ("external launcher" if world > 1 else "single process")),
+                       "conv_precision": os.environ.get("DSM_CONV_PRECISION", "bf16x3") +
+                                         " (DSM_CONV_PRECISION=fp32 keeps the fp32-input MFMA)"},
+            # rank 0's per-step GPU time from one HIP event per step inside the timed region
+            "step_ms": {"median": round(statistics.median(step_ms), 3), "min": round(min(step_ms), 3),
+                        "max": round(max(step_ms), 3), "mean_wall": round(ms_per_step, 3)},
         }
         if timer is not None:
             roofs = kernel_rooflines(timer.summary(), args.steps)
             dominant = max(roofs, key=lambda k: roofs[k]["ms_per_step"])
             result["roofline"] = dict(roofs[dominant], kernel=dominant)
+            vol = roofs.get("volume_ndhwc_fwd_kernel") or roofs.get("volume_s3_fwd_kernel")
+            if vol is not None and volume_b2b_us:
+                vol["back_to_back_us"] = round(volume_b2b_us, 2)
+                vol["back_to_back_frac"] = round(vol["work_per_launch"] / (volume_b2b_us * 1e-6) / 1e9
+                                                 / PEAK_HBM_GBS, 4)
             result["rooflines"] = roofs
             hip_ms = sum(v["ms_per_step"] for v in roofs.values())
             result["hip_path_ms_per_step"] = round(hip_ms, 3)
+            stages = {}
+            for v in roofs.values():
+                stages[v["stage"]] = round(stages.get(v["stage"], 0.0) + v["ms_per_step"], 4)
+            result["stage_ms_per_step"] = stages
             # stock torch ops, launch gaps and the event records themselves, in the instrumented pass
             result["other_ms_per_step"] = round(instrumented / args.steps * 1e3 - hip_ms, 3)
             result["kernel_timing"] = {

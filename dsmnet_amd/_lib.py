@@ -46,6 +46,7 @@ SIGNATURES = {
     "dsm_conv3d_plan": (c_int, [ctypes.POINTER(Conv3dArgs), ctypes.c_char_p, c_int]),
     "dsm_conv3d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     "dsm_conv3d_cout1_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "dsm_deconv3d_cout1_bwd": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "dsm_volume_relayout": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
     "dsm_conv_packed_weight_bytes": (ctypes.c_size_t, [c_int] * 4),
     "dsm_spp_branch_floats": (ctypes.c_size_t, [c_int] * 3),

@@ -16,8 +16,20 @@ from . import costvolume as cv
 RELU_NONE, RELU_AFTER_ADD, RELU_BEFORE_ADD = 0, 1, 2
 
 
+_EPOCH = [0]
+
+
+def invalidate_folded_caches():
+    """Drop every cached packed weight / folded BN affine (3-D blocks, 2-D blocks, SPP head):
+    they are re-made at the next forward.  The caches notice ordinary updates by themselves
+    (optimizer steps, ``load_state_dict``, ``with torch.no_grad(): w.mul_(...)`` -- all bump the
+    tensor's ``_version``); an in-place edit THROUGH ``.data`` (``w.data.mul_()``) does not, and
+    needs this call afterwards.  Exported as ``dsmnet_amd.refold()``."""
+    _EPOCH[0] += 1
+
+
 def _versions(*tensors):
-    return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+    return tuple((t.data_ptr(), t._version) for t in tensors if t is not None) + (_EPOCH[0],)
 
 
 class _Folded(object):
@@ -185,3 +197,40 @@ class Chain3d(nn.Sequential):
                 raise TypeError("unsupported layer in a 3-D chain: %r" % (m,))
             i += 2 if nxt_relu else 1
         return x
+
+
+class Conv3dHip(nn.Conv3d):
+    """A bare ``nn.Conv3d`` (k3, p1) whose forward runs on the HIP kernel; state-dict keys are
+    the stock ``weight`` / ``bias``.  A real subclass (not a rebound ``forward``): deep copies,
+    pickling and ``torch.save(model)`` see an ordinary module with its own fold cache."""
+
+    def __init__(self, *args, **kw):
+        super(Conv3dHip, self).__init__(*args, **kw)
+        _check_conv(self)
+        self._folded = _Folded()
+
+    def forward(self, x, residual=None, relu=False):
+        return run_block(self._folded, self, None, x, residual, RELU_AFTER_ADD if relu else RELU_NONE)
+
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        import copy
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = _Folded() if k == "_folded" else copy.deepcopy(v, memo)
+        return new
+
+
+class ConvTranspose3dHip(nn.ConvTranspose3d):
+    """``nn.ConvTranspose3d`` (k3, s2, p1, op1) on the HIP kernel -- GCNet's ``l37``
+    (models/gcnet.py:63)."""
+
+    def __init__(self, *args, **kw):
+        super(ConvTranspose3dHip, self).__init__(*args, **kw)
+        _check_conv(self)
+        self._folded = _Folded()
+
+    def forward(self, x, residual=None, relu=False):
+        return run_block(self._folded, self, None, x, residual, RELU_AFTER_ADD if relu else RELU_NONE)
+
+    __deepcopy__ = Conv3dHip.__deepcopy__

@@ -219,7 +219,10 @@ class SoftArgminFunction(torch.autograd.Function):
         need_grad = ctx.needs_input_grad[0]
         stats = torch.empty((B, 2, H, W), device=cost.device, dtype=cost.dtype) if need_grad else None
         lib = _lib.load()
-        with torch.cuda.device(cost.device), _timed("soft_argmin_fwd_kernel", 4.0 * B * (Dc * Hc * Wc + H * W)):
+        # the x4 fast path (soft_argmin.hip: dsm_soft_argmin_fwd) has its own kernel
+        kname = ("soft_argmin_up4_kernel" if (D == 4 * Dc and (Hc, Wc) != (H, W) and not align_corners)
+                 else "soft_argmin_fwd_kernel")
+        with torch.cuda.device(cost.device), _timed(kname, 4.0 * B * (Dc * Hc * Wc + H * W)):
             rc = lib.dsm_soft_argmin_fwd(_p(c4), _p(disp), _p(stats), B, Dc, Hc, Wc, D, H, W,
                                          int(negate), int(align_corners), _lib.DSM_F32, _stream())
         _lib.check(rc, "dsm_soft_argmin_fwd")
@@ -519,7 +522,18 @@ class Conv3dFunction(torch.autograd.Function):
         cout = gy.shape[1]
         dx = dw = db = None
         w = weight.detach()
-        if cout == 1:                                   # classifier head, stride 1, not transposed
+        if cout == 1 and transposed:                    # GCNet's head l37: ConvTranspose3d(C -> 1, s2)
+            dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+            with torch.cuda.device(x.device):
+                rc = _lib.load().dsm_deconv3d_cout1_bwd(
+                    _p(x), _p(gy), _p(w.contiguous()), _p(dx), _p(dw), B, cin, x.shape[2],
+                    x.shape[3], x.shape[4], gy.shape[2], gy.shape[3], gy.shape[4], _stream())
+            _lib.check(rc, "dsm_deconv3d_cout1_bwd")
+        elif cout == 1 and stride != 1:
+            raise NotImplementedError("Conv3dFunction.backward: a stride-%d convolution to one "
+                                      "channel is not a layer of the reference" % stride)
+        elif cout == 1:                                 # classifier head, stride 1, not transposed
             packed = pack_conv3d_weight(w, False)       # [27][Cin]
             dwt = torch.empty(27 * cin, device=x.device, dtype=torch.float32)
             dx = torch.empty_like(x)

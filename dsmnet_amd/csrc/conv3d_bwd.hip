@@ -185,6 +185,74 @@ __global__ __launch_bounds__(256) void cout1_bwd_weight_kernel(const float* __re
   }
 }
 
+
+// ----------------------------------------------------------------------------
+// ConvTranspose3d(C -> 1, k3, s2, p1, op1) backward -- GCNet's head l37 (models/gcnet.py:63,98).
+// Output position o = 2 i - 1 + k per axis.  g: (B,Do,Ho,Wo); x: (B,Di,Hi,Wi,C) NDHWC;
+// w: torch layout (C,1,27).  VALU kernels: the layer is 2.7 GMAC at GCNet's full size.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void deconv_cout1_bwd_data_kernel(
+    const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dx, int B, int C,
+    int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
+  extern __shared__ float wt[];                       // [27][C]
+  for (int u = threadIdx.x; u < 27 * C; u += 256) wt[(u % 27) * C + u / 27] = w[u];
+  __syncthreads();
+  const long n = (long)B * Di * Hi * Wi * (C / 4);
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int q = i % (C / 4);
+  long v = i / (C / 4);
+  const int x = v % Wi; v /= Wi;
+  const int y = v % Hi; v /= Hi;
+  const int z = v % Di; const int b = v / Di;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int tap = 0; tap < 27; ++tap) {
+    const int oz = 2 * z - 1 + tap / 9, oy = 2 * y - 1 + (tap / 3) % 3, ox = 2 * x - 1 + tap % 3;
+    if (oz < 0 || oz >= Do || oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
+    const float gv = g[(((long)b * Do + oz) * Ho + oy) * Wo + ox];
+    a += gv * *reinterpret_cast<const f32x4*>(wt + tap * C + q * 4);
+  }
+  *reinterpret_cast<f32x4*>(dx + i * 4) = a;
+}
+
+// dw[c][tap] = sum_i x[i][c] g[2 i - 1 + tap]; thread = (voxel lane, channel), 27 running sums
+// each, voxel lanes folded through LDS, one atomic per (c, tap) per block.
+__global__ __launch_bounds__(256) void deconv_cout1_bwd_weight_kernel(
+    const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ dw, int B, int C,
+    int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
+  __shared__ float red[256 * 27];
+  const int nvl = 256 / C;
+  const int c = threadIdx.x % C, vl = threadIdx.x / C;
+  float acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+  const long nvox = (long)B * Di * Hi * Wi;
+  if (vl < nvl) {
+    for (long v = (long)blockIdx.x * nvl + vl; v < nvox; v += (long)gridDim.x * nvl) {
+      long r = v;
+      const int xx = r % Wi; r /= Wi;
+      const int yy = r % Hi; r /= Hi;
+      const int zz = r % Di; const int b = r / Di;
+      const float xv = x[v * C + c];
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        const int oz = 2 * zz - 1 + t / 9, oy = 2 * yy - 1 + (t / 3) % 3, ox = 2 * xx - 1 + t % 3;
+        if (oz < 0 || oz >= Do || oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
+        acc[t] = fmaf(xv, g[(((long)b * Do + oz) * Ho + oy) * Wo + ox], acc[t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 27; ++t) red[threadIdx.x * 27 + t] = acc[t];
+  __syncthreads();
+  for (int u = threadIdx.x; u < 27 * C; u += 256) {
+    const int cc = u / 27, t = u % 27;
+    float s = 0.f;
+    for (int l = 0; l < nvl; ++l) s += red[(l * C + cc) * 27 + t];
+    atomicAdd(dw + u, s);
+  }
+}
+
 }  // namespace
 
 // x: (B,Dx,Hx,Wx,Cx) NDHWC; g: (B,Dg,Hg,Wg,Cg); stride: X positions per G position (1 or 2);
@@ -256,6 +324,38 @@ extern "C" int dsm_conv3d_cout1_bwd(const void* x, const void* g, const void* w_
       return DSM_ERR_LAUNCH;
     hipLaunchKernelGGL(cout1_bwd_weight_kernel, dim3(B * D * H), dim3(256), 0, s, (const float*)x,
                        (const float*)g, (float*)dw_tapmajor, B, C, D, H, W);
+  }
+  return dsm_launch_status();
+}
+
+// ConvTranspose3d(C -> 1, k3, s2, p1, op1) backward: g (B,Do,Ho,Wo); x (B,Di,Hi,Wi,C) NDHWC;
+// w: torch layout (C,1,3,3,3); dx (B,Di,Hi,Wi,C) or NULL; dw (C,1,3,3,3) or NULL (overwritten).
+extern "C" int dsm_deconv3d_cout1_bwd(const void* x, const void* g, const void* w, void* dx,
+                                      void* dw, int B, int C, int Di, int Hi, int Wi, int Do,
+                                      int Ho, int Wo, dsm_stream_t stream) {
+  DSM_REQUIRE(g && (dx || dw), DSM_ERR_ARG);
+  DSM_REQUIRE(B > 0 && C > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0, DSM_ERR_ARG);
+  DSM_REQUIRE(C % 4 == 0 && C <= 256, DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(Do <= 2 * Di && Ho <= 2 * Hi && Wo <= 2 * Wi, DSM_ERR_ARG);
+  hipStream_t s = (hipStream_t)stream;
+  dsm_clear_stale_error();
+  if (dx) {
+    DSM_REQUIRE(w, DSM_ERR_ARG);
+    const long n = (long)B * Di * Hi * Wi * (C / 4);
+    DSM_REQUIRE(n / 256 < 0x7fffffffL, DSM_ERR_UNSUPPORTED);
+    hipLaunchKernelGGL(deconv_cout1_bwd_data_kernel, dim3(dsm_cdiv(n, 256)), dim3(256),
+                       (size_t)27 * C * sizeof(float), s, (const float*)g, (const float*)w,
+                       (float*)dx, B, C, Di, Hi, Wi, Do, Ho, Wo);
+  }
+  if (dw) {
+    DSM_REQUIRE(x, DSM_ERR_ARG);
+    if (hipMemsetAsync(dw, 0, (size_t)27 * C * sizeof(float), s) != hipSuccess) return DSM_ERR_LAUNCH;
+    const long nvox = (long)B * Di * Hi * Wi;
+    const int nvl = 256 / C;
+    long blocks = (nvox + nvl - 1) / nvl;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(deconv_cout1_bwd_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                       (const float*)x, (const float*)g, (float*)dw, B, C, Di, Hi, Wi, Do, Ho, Wo);
   }
   return dsm_launch_status();
 }

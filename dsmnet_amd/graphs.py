@@ -58,10 +58,17 @@ class GraphedTrainStep(object):
     share it.  ``step = GraphedTrainStep(model, optim, lossfun, batch)``;
     ``loss, disps = step(next_batch)`` (static tensors).
     The optimizer must be built with ``capturable=True``; single process only (a captured
-    gradient all-reduce is not wired up).  Capture before any eager backward through this model,
-    or drop every reference to earlier losses/outputs first (``del loss; gc.collect()``): an
-    autograd node kept alive from a step on another stream invalidates the capture, and the HIP
-    runtime then crashes in ``capture_end`` instead of raising."""
+    gradient all-reduce is not wired up).
+
+    An eager backward through the same model before the capture leaves gradient tensors and
+    autograd buffers that were allocated OUTSIDE the capture's private pool, on the default
+    stream; re-used inside the capture (``.grad`` accumulation, a freed block handed back by the
+    caching allocator with a pending cross-stream event) they invalidate it, and the HIP runtime
+    aborted in ``capture_end`` instead of raising.  The constructor therefore drops every
+    gradient, collects garbage (dead autograd graphs release their buffers) and synchronises
+    the device before the side-stream warm-up and again before the capture, so that the capture
+    starts from allocations of its own (tests/test_models_gpu.py:
+    ``test_graphed_train_step_after_an_eager_step_on_the_same_model``)."""
 
     def __init__(self, model, optim, lossfun, example_batch, warmup=3):
         import torch.distributed as dist
@@ -75,16 +82,27 @@ class GraphedTrainStep(object):
         lossfun.capturable = True
         model.train()
         self.batch = example_batch[:, :7].clone()
+        self._quiesce()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
+        self._quiesce()
         self.graph = torch.cuda.CUDAGraph()
-        optim.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.loss, self.disps = self._step()
+
+    def _quiesce(self):
+        """No gradient, no dead autograd graph, no kernel in flight: the state a capture (or the
+        warm-up on the side stream) must start from."""
+        import gc
+        self.optim.zero_grad(set_to_none=True)
+        for p in self.model.parameters():
+            p.grad = None
+        gc.collect()
+        torch.cuda.synchronize()
 
     def _step(self):
         b = self.batch

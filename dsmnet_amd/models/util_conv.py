@@ -11,7 +11,7 @@ import math
 import torch.nn as nn
 
 from .. import costvolume as cv
-from ..blocks3d import ConvBN3d
+from ..blocks3d import Conv3dHip, ConvBN3d, ConvTranspose3dHip
 
 flag_bn = False
 flag_bias_default = True
@@ -74,10 +74,11 @@ def deconv2d_bn(in_planes, out_planes, kernel_size=4, stride=2, flag_bias=flag_b
 def conv3d_bn(in_planes, out_planes, kernel_size=3, stride=1, flag_bias=flag_bias_default,
               bn=flag_bn, activefun=activefun_default):
     """3-D conv + BN + activation as ONE fused block (children '0','1','2' as in the reference)."""
+    if not bn and not activefun:
+        return Conv3dHip(in_planes, out_planes, kernel_size, stride,
+                         padding=(kernel_size - 1) // 2, bias=flag_bias)
     conv = nn.Conv3d(in_planes, out_planes, kernel_size, stride, padding=(kernel_size - 1) // 2,
                      bias=flag_bias)
-    if not bn and not activefun:
-        return _Bare3d.adopt(conv)
     return ConvBN3d(conv, nn.BatchNorm3d(out_planes) if bn else None, activefun or None)
 
 
@@ -88,29 +89,12 @@ def deconv3d_bn(in_planes, out_planes, kernel_size=4, stride=2, flag_bias=flag_b
     what is meant, i.e. BatchNorm3d -- identical parameters and state-dict keys."""
     assert stride > 1
     p = (kernel_size - 1) // 2
+    if not bn and not activefun:
+        return ConvTranspose3dHip(in_planes, out_planes, kernel_size, stride, padding=p,
+                                  output_padding=stride - (kernel_size - 2 * p), bias=flag_bias)
     conv = nn.ConvTranspose3d(in_planes, out_planes, kernel_size, stride, padding=p,
                               output_padding=stride - (kernel_size - 2 * p), bias=flag_bias)
-    if not bn and not activefun:
-        return _Bare3d.adopt(conv)
     return ConvBN3d(conv, nn.BatchNorm3d(out_planes) if bn else None, activefun or None)
-
-
-class _Bare3d(object):
-    """A bare nn.Conv3d / nn.ConvTranspose3d whose forward runs on the HIP kernel.  The module
-    itself is returned (so its state-dict keys are `name.weight`, `name.bias` as in the
-    reference, gcnet.py:63 `l37`); only `forward` is rebound."""
-
-    @staticmethod
-    def adopt(conv):
-        from ..blocks3d import _Folded, _check_conv, run_block
-        _check_conv(conv)
-        folded = _Folded()
-
-        def forward(x, residual=None, relu=False):
-            return run_block(folded, conv, None, x, residual, 1 if relu else 0)
-
-        conv.forward = forward
-        return conv
 
 
 class BasicBlock(nn.Module):

@@ -66,26 +66,32 @@ def gather_disparities(local, idx, num_pairs, world):
     return out
 
 
-def allreduce_gradients(parameters, world=None):
+def allreduce_gradients(parameters, world=None, extra=None):
     """Average gradients across ranks with ONE flat all-reduce (sum, then / world).
     Parameters without a gradient contribute zeros so that every rank reduces the same
-    buffer.  Returns the number of elements reduced."""
+    buffer -- every rank must call this every step, whatever its own batch held.
+    ``extra``: an optional 1-D float tensor that rides in the same bucket and comes back
+    SUMMED over ranks (not averaged) -- e.g. the count of ranks whose batch had ground truth.
+    Returns the number of gradient elements reduced, or ``(that, extra_sum)`` with ``extra``."""
     if world is None:
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     params = [p for p in parameters if p.requires_grad]
     if world == 1 or not params:
-        return 0
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
-                      for p in params])
+        return 0 if extra is None else (0, extra.clone())
+    parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]
+    if extra is not None:
+        parts.append(extra.to(parts[0].dtype).reshape(-1))
+    flat = torch.cat(parts)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.div_(world)
     off = 0
     for p in params:
         n = p.numel()
-        g = flat[off: off + n].view_as(p)
+        g = flat[off: off + n].view_as(p) / world
         if p.grad is None:
             p.grad = g.clone()
         else:
             p.grad.copy_(g)
         off += n
-    return off
+    if extra is None:
+        return off
+    return off, flat[off:].clone()

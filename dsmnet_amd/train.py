@@ -146,21 +146,48 @@ def _split(batch):
     return batch[:, :3], batch[:, 3:6], batch[:, 6:7]
 
 
+def _world(world):
+    import torch.distributed as dist
+    if world is not None:
+        return world
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 def train_step(model, optim, lossfun, batch, world=None):
     """One iteration of stereo_supervised.py:53-97: forward in train mode, pyramid loss with
     ``flag_smooth=True``, backward, (multi-GPU: one flat gradient all-reduce), Adam step.
     ``batch`` = (B,7,H,W) imL | imR | dispL, as the reference's loader yields it.
-    Returns (loss, D1, EPE) as floats."""
+    Returns (loss, D1, EPE) as floats.
+
+    Single process: a batch without any ground-truth pixel gives the reference's integer-0 loss
+    and the step is skipped, as there (losses/loss.py:330-331).  Several ranks: EVERY rank runs
+    backward and the all-reduce every step (the loss is the tensor form, zero -- with zero
+    gradients -- on a rank without ground truth), so the collective calls always match; the
+    number of ranks that had ground truth rides in the same bucket and the optimizer step is
+    skipped on all ranks together when it is zero."""
     model.train()
+    world = _world(world)
     imL, imR, dispL = _split(batch)
     scale_dispLs, dispLs = model(imL, imR)
-    loss = lossfun({"disp_gt": dispL, "disps": dispLs, "scale_disps": scale_dispLs,
-                    "flag_smooth": True})
+    args = {"disp_gt": dispL, "disps": dispLs, "scale_disps": scale_dispLs, "flag_smooth": True}
     optim.zero_grad()
-    if torch.is_tensor(loss):              # the integer 0 when no pixel has ground truth
+    if world > 1:
+        was = lossfun.capturable
+        lossfun.capturable = True               # tensor loss on every rank, no host-side branch
+        try:
+            loss = lossfun(args)
+        finally:
+            lossfun.capturable = was
         loss.backward()
-        sharding.allreduce_gradients(model.parameters(), world=world)
-        optim.step()
+        has_gt = (dispL > 0).any().to(torch.float32).reshape(1)
+        _, n_gt = sharding.allreduce_gradients(model.parameters(), world=world, extra=has_gt)
+        if float(n_gt) > 0:
+            optim.step()
+    else:
+        loss = lossfun(args)
+        if torch.is_tensor(loss):              # the integer 0 when no pixel has ground truth
+            loss.backward()
+            optim.step()
     d1, epe = accuracy(dispLs[0].detach(), dispL)
     return float(loss.detach() if torch.is_tensor(loss) else loss), float(d1), float(epe)
 

@@ -190,6 +190,14 @@ int dsm_conv3d_cout1_bwd(const void* x, const void* g, const void* w_packed, voi
                          void* dw_tapmajor, int B, int C, int D, int H, int W,
                          dsm_stream_t stream);
 
+/* ConvTranspose3d(C -> 1, k3, s2, p1, op1) backward -- GCNet's head l37 (models/gcnet.py:63,98;
+ * autograd through nn.ConvTranspose3d in the reference).  g (B,Do,Ho,Wo); x (B,Di,Hi,Wi,C)
+ * NDHWC; w: torch layout (C,1,3,3,3); dx (B,Di,Hi,Wi,C) or NULL; dw (C,1,3,3,3) or NULL,
+ * overwritten.  C % 4 == 0, C <= 256. */
+int dsm_deconv3d_cout1_bwd(const void* x, const void* g, const void* w, void* dx, void* dw,
+                           int B, int C, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                           dsm_stream_t stream);
+
 /* NCDHW <-> NDHWC repack of an fp32 volume (used at the boundary with stock
  * torch modules that want contiguous NCDHW). to_ndhwc = 1: src NCDHW. */
 int dsm_volume_relayout(const void* src, void* dst, int B, int C, int D, int H, int W,

@@ -13,7 +13,8 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 torch.manual_seed(0)
 m = model_create_by_name("psmnet", 192).cuda().train()
 for i in (1, 2, 3):
-    getattr(m, "classif%d" % i)[2].weight.data.mul_(1e-3)
+    with torch.no_grad():
+        getattr(m, "classif%d" % i)[2].weight.mul_(1e-3)
 left = torch.rand(B, 3, H, W, device="cuda")
 right = torch.roll(left, -6, dims=3)
 target = torch.full((B, H, W), 6.0, device="cuda")

@@ -28,6 +28,7 @@ def cv(hip_lib):
     (32, 64, 2, False, (1, 6, 12, 40), False), (64, 64, 2, False, (1, 5, 9, 37), True),
     (64, 64, 2, True, (1, 3, 6, 20), False), (64, 32, 2, True, (1, 3, 5, 33), True),
     (32, 1, 1, False, (1, 5, 9, 37), False),
+    (32, 1, 2, True, (1, 4, 7, 19), True),          # GCNet's head l37 (gcnet.py:63): ADVICE r1
 ])
 def test_conv3d_function_gradients(cv, cin, cout, stride, transposed, shape, bias):
     B, D, H, W = shape
@@ -53,21 +54,43 @@ def test_conv3d_function_gradients(cv, cin, cout, stride, transposed, shape, bia
         assert maxerr(g, r) <= tol, "%s: %.3e > %.3e" % (name, maxerr(g, r), tol)
 
 
-def _trunk_step_errors(seed):
-    """Relative max-abs error of every checked gradient for one seeded input, plus the loss and
-    running-statistics checks."""
+class _SignLog(object):
+    """Records the sign pattern of every tensor that enters a ReLU (as CPU bool masks)."""
+
+    def __init__(self):
+        self.masks = []
+
+    def wrap(self, fn):
+        def relu(x, *a, **k):
+            self.masks.append((x.detach() > 0).cpu())
+            return fn(x, *a, **k)
+        return relu
+
+
+def _trunk_step_errors(seed, hw=(16, 40), d4=8):
+    """One train-mode trunk + heads step on a seeded input: relative max-abs error of every
+    checked gradient, and the number of ReLU inputs whose SIGN differs between the two
+    implementations (a unit within rounding distance of zero can take the other side)."""
+    import torch.nn.functional as TF
+    from dsmnet_amd import blocks3d
     from dsmnet_amd import costvolume as cv
     from dsmnet_amd.models import model_create_by_name
     sd = randomise_bn(OM.init_state("psmnet", 0), 41)
     OM.apply_head_scale("psmnet", sd, 0.05)
-    fl, fr = seeded(seed, 1, 32, 16, 40), seeded(seed + 1, 1, 32, 16, 40)
-    size = (32, 64, 160)
+    fl, fr = seeded(seed, 1, 32, *hw), seeded(seed + 1, 1, 32, *hw)
+    size = (4 * d4, 4 * hw[0], 4 * hw[1])
     # oracle: leaves that require grad
     osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
                else v.clone()) for k, v in sd.items()}
     ofl, ofr = fl.clone().requires_grad_(True), fr.clone().requires_grad_(True)
     n = OM.Net(osd, training=True)
-    costs = OM.psmnet_trunk(n, OO.concat_volume(ofl, ofr, 8, True))
+    olog, glog = _SignLog(), _SignLog()
+    orig = TF.relu
+    TF.relu = olog.wrap(orig)                      # the oracle's trunk calls F.relu
+    try:
+        costs = OM.psmnet_trunk(n, OO.concat_volume(ofl, ofr, d4, True))
+    finally:
+        TF.relu = orig
     oloss = sum(OO.soft_argmin(c, size).mean() for c in costs)
     keys = ["dres0.0.0.weight", "dres0.0.1.weight", "dres1.2.0.weight", "dres2.conv1.0.0.weight",
             "dres2.conv5.0.weight", "dres3.conv6.0.weight", "dres4.conv2.1.bias",
@@ -78,39 +101,63 @@ def _trunk_step_errors(seed):
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
     gfl, gfr = fl.cuda().requires_grad_(True), fr.cuda().requires_grad_(True)
-    gc = m.regularise(cv.concat_volume(gfl, gfr, 8, True))
+    orig_t = torch.relu
+    torch.relu = glog.wrap(orig_t)                 # blocks3d's train-mode blocks call torch.relu
+    try:
+        gc = m.regularise(cv.concat_volume(gfl, gfr, d4, True))
+    finally:
+        torch.relu = orig_t
+    assert blocks3d.torch.relu is orig_t
     loss = sum(cv.soft_argmin(c, size).mean() for c in gc)
     assert abs(loss.item() - oloss.item()) <= 1e-3 * max(1.0, abs(oloss.item()))
     for a, b in zip(gc, costs):                                   # train-mode forward: tight
         assert maxerr(a, b) <= 2e-5 * b.abs().max().item()
+    assert len(olog.masks) == len(glog.masks) == 21, (len(olog.masks), len(glog.masks))
+    flips = 0
+    for a, b in zip(olog.masks, glog.masks):
+        assert a.shape == b.shape
+        flips += int((a != b).sum())
     params = dict(m.named_parameters())
     ggr = torch.autograd.grad(loss, [params[k] for k in keys] + [gfl, gfr])
     # running statistics were updated as nn.BatchNorm3d does
     assert maxerr(m.dres0[0][1].running_mean, osd["dres0.0.1.running_mean"]) <= 1e-4
-    return {k: maxerr(g, r) / max(r.abs().max().item(), 1e-6)
+    errs = {k: maxerr(g, r) / max(r.abs().max().item(), 1e-6)
             for k, g, r in zip(keys + ["fL", "fR"], ggr, ogr)}
+    return errs, flips
+
+
+def _check_against_flips(errs, flips, nvox_min):
+    """No flipped unit: every gradient within 2e-3 (measured 3e-6).  Each flipped unit may move
+    the gradients of a BatchNorm layer that sees ``nvox_min`` voxels per channel by ~1/nvox_min
+    (it changes one term of that channel's batch statistics); allow twice that per flip."""
+    worst = max(errs.values())
+    bound = 2e-3 + flips * 2.0 / nvox_min
+    assert flips <= 16, "too many sign flips (%d) for rounding noise: %r" % (flips, errs)
+    assert worst <= bound, "flips=%d bound=%.3e: %r" % (flips, bound, errs)
 
 
 def test_psmnet_trunk_training_step_vs_oracle(hip_lib):
     """Train-mode forward + backward through the whole 3-D trunk and the three fused heads:
-    parameter and input gradients against the oracle's CPU autograd.
+    parameter and input gradients against the oracle's CPU autograd, on three seeds.
 
     The forward agrees to ~3e-6 on every input.  The backward of a ReLU network is discontinuous:
     an activation within rounding distance of zero can take the other side in the two
-    implementations, and one flipped unit in a BatchNorm layer that sees 80 voxels per channel
-    moves that layer's gradients by ~1 %.  That happens for about one seed in three, with the
-    fp32-input MFMA as with the bf16x3 kernels (tests/tools/grad_check.py: seeds 71/81/91/101).  So:
-    every seed must stay within the bound a few flips can explain, and at least one must be
-    flip-free, where all gradients agree to 2e-3 (measured: 3e-6).  A wrong backward kernel fails
-    both."""
-    clean = False
+    implementations (about one seed in three, with the fp32-input MFMA as with the bf16x3
+    kernels).  The test therefore COUNTS those units (sign pattern of every ReLU input in both
+    implementations) and bounds each seed's error by what that many flips can explain; a seed
+    without flips must agree to 2e-3.  The smallest BN layer here sees 2x4x10 = 80 voxels."""
     for seed in (81, 71, 101):
-        errs = _trunk_step_errors(seed)
-        assert max(errs.values()) <= 0.2, errs
-        if max(errs.values()) <= 2e-3:
-            clean = True
-            break
-    assert clean, errs
+        errs, flips = _trunk_step_errors(seed)
+        _check_against_flips(errs, flips, 80)
+
+
+def test_psmnet_trunk_training_step_at_config5_shape(hip_lib):
+    """BASELINE config #5's own 1/4-resolution shape, one pair: features (1,32,135,240), D/4 = 48
+    (540x960, D=192).  The odd sizes exercise the crop of ``myadd_3d`` on every level
+    (135 -> 68 -> 34 -> 68 -> 136 vs 135; stackhourglass.py:10-20) in forward AND backward.
+    Gradients against the oracle's CPU autograd, bounded by the counted ReLU sign flips."""
+    errs, flips = _trunk_step_errors(91, hw=(135, 240), d4=48)
+    _check_against_flips(errs, flips, 12 * 34 * 60)
 
 
 def test_psmnet_full_training_step(hip_lib):
@@ -123,7 +170,8 @@ def test_psmnet_full_training_step(hip_lib):
     torch.manual_seed(0)
     m = model_create_by_name("psmnet", 192).cuda().train()
     for i in (1, 2, 3):                                   # sane logit scale for a random init
-        getattr(m, "classif%d" % i)[2].weight.data.mul_(1e-3)
+        with torch.no_grad():
+            getattr(m, "classif%d" % i)[2].weight.mul_(1e-3)
     g = torch.Generator().manual_seed(5)
     left = torch.rand(1, 3, 256, 512, generator=g).cuda()
     right = torch.roll(left, -6, dims=3)
@@ -146,3 +194,72 @@ def test_psmnet_full_training_step(hip_lib):
     l1 = step()
     assert torch.isfinite(l0) and torch.isfinite(l1)
     assert l1.item() < l0.item(), (l0.item(), l1.item())
+
+
+def _config5_batch(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    left = torch.rand(B, 3, 540, 960, generator=g)
+    right = torch.roll(left, -9, dims=3)
+    disp = torch.full((B, 1, 540, 960), 9.0)
+    disp[:, :, :, :9] = 0
+    return torch.cat([left, right, disp], 1).cuda()
+
+
+def test_config5_psmnet_train_step_540x960_four_pairs(hip_lib):
+    """BASELINE config #5 at its real per-GPU shape: ``train.train_step`` on PSMNet, 540x960,
+    D=192, 4 pairs on one GPU (the share of batch 32 over 8 GPUs; the gradient all-reduce of
+    the other 7 is covered by the world-size-2 gloo tests).  fp32, as the reference computes
+    (stackhourglass.py:124) -- see DESIGN.md on config #5's "fp16".  Checks: the volume
+    convolution (4,64,48,135,240) = 1.59 GB stays on the bf16x3 plan (just under the 2 GiB
+    limit of its 32-bit offsets), every parameter gets a finite gradient, the loss is finite
+    and decreases over Adam steps on the same batch, peak memory is reported."""
+    import ctypes
+    from dsmnet_amd import _lib, costvolume as cv, train
+    from dsmnet_amd.models import model_create_by_name
+    a = _lib.Conv3dArgs()
+    a.B, a.Cin, a.Cout = 4, 64, 32
+    a.Di, a.Hi, a.Wi = 48, 135, 240
+    a.Do, a.Ho, a.Wo = 48, 135, 240
+    a.stride, a.transposed, a.relu = 1, 0, 0
+    a.x = a.w_packed = a.y = 16                       # the plan looks at shapes only
+    assert "bf16x3" in cv.conv3d_plan_name(a), cv.conv3d_plan_name(a)
+    torch.manual_seed(0)
+    model = model_create_by_name("psmnet", 192).cuda()
+    for i in (1, 2, 3):
+        with torch.no_grad():
+            getattr(model, "classif%d" % i)[2].weight.mul_(1e-3)
+    lossfun = train.losses("supervised", model.count_levels, 0)
+    lossfun.Weight_Adjust_levels(0)
+    opt = train.make_optimizer(model, lr=1e-3)
+    batch = _config5_batch(4, 11)
+    torch.cuda.reset_peak_memory_stats()
+    losses = [train.train_step(model, opt, lossfun, batch)[0] for _ in range(3)]
+    assert all(l == l and abs(l) < 1e6 for l in losses), losses
+    assert losses[-1] < losses[0], losses
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    print("config #5 step: losses %s, peak memory %.1f GiB" % (["%.4f" % l for l in losses], peak))
+    assert peak < 200.0
+
+
+def test_gcnet_train_step(hip_lib):
+    """One supervised step through GCNet: the transposed 32 -> 1 head ``l37``
+    (gcnet.py:63,98) has its own backward kernels; every parameter gets a finite gradient and
+    the loss goes down."""
+    from dsmnet_amd import train
+    from dsmnet_amd.models import model_create_by_name
+    torch.manual_seed(0)
+    model = model_create_by_name("gcnet", 64).cuda()
+    with torch.no_grad():
+        model.layer3d.l37.weight.mul_(0.05)
+    lossfun = train.losses("supervised", model.count_levels, 0)
+    lossfun.Weight_Adjust_levels(0)
+    opt = train.make_optimizer(model, lr=1e-3)
+    g = torch.Generator().manual_seed(3)
+    left = torch.rand(1, 3, 64, 128, generator=g)
+    right = torch.roll(left, -5, dims=3)
+    disp = torch.full((1, 1, 64, 128), 5.0)
+    batch = torch.cat([left, right, disp], 1).cuda()
+    losses = [train.train_step(model, opt, lossfun, batch)[0] for _ in range(4)]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    assert losses[-1] < losses[0], losses

@@ -131,3 +131,66 @@ def test_train_step_world_size_2_equals_averaged_gradients():
     for r in (0, 1):
         for got, w in zip(results[r], want):
             assert torch.allclose(torch.from_numpy(got), w, atol=1e-6)
+
+
+def _empty_gt_worker(rank, world, port, q, empty_ranks):
+    from dsmnet_amd import train
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sharding.init_from_env("gloo")
+    torch.manual_seed(0)
+    model = _ToyStereo()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    lossfun = train.losses("supervised", 2, 4)
+    lossfun.Weight_Adjust_levels(1)
+    b = _batch(100 + rank)
+    if rank in empty_ranks:
+        b[:, 6:7] = 0                       # no pixel with ground truth on this rank
+    loss, _, _ = train.train_step(model, opt, lossfun, b)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, loss, [p.detach().numpy().copy() for p in model.parameters()]))
+
+
+def _run_empty_gt(empty_ranks):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_gt_worker, args=(r, 2, port, q, empty_ranks)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {r: (loss, params) for r, loss, params in (q.get(timeout=120) for _ in procs)}   # a hang fails here
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+def test_train_step_with_one_rank_without_ground_truth_does_not_deadlock():
+    """a rank whose batch has no gt > 0 pixel used to skip backward AND the
+    all-reduce while the other rank waited in it.  Now every rank reduces every step; the
+    empty rank contributes zero gradients and the parameters stay identical across ranks."""
+    from dsmnet_amd import train
+    results = _run_empty_gt({1})
+    assert results[1][0] == 0.0 and results[0][0] > 0.0
+    torch.manual_seed(0)
+    model = _ToyStereo()
+    lossfun = train.losses("supervised", 2, 4)
+    lossfun.Weight_Adjust_levels(1)
+    b = _batch(100)
+    s, d = model(b[:, :3], b[:, 3:6])
+    lossfun({"disp_gt": b[:, 6:7], "disps": d, "scale_disps": s, "flag_smooth": True}).backward()
+    want = [p.detach() - 0.1 * p.grad / 2 for p in model.parameters()]     # (g0 + 0) / 2
+    for r in (0, 1):
+        for got, w in zip(results[r][1], want):
+            assert torch.allclose(torch.from_numpy(got), w, atol=1e-6)
+
+
+def test_train_step_with_no_ground_truth_anywhere_skips_the_step_on_all_ranks():
+    results = _run_empty_gt({0, 1})
+    torch.manual_seed(0)
+    untouched = [p.detach() for p in _ToyStereo().parameters()]
+    for r in (0, 1):
+        assert results[r][0] == 0.0
+        for got, w in zip(results[r][1], untouched):
+            assert torch.equal(torch.from_numpy(got), w)

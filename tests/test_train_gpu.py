@@ -47,7 +47,8 @@ def test_psmnet_train_step_and_lr_schedule(hip_lib):
     torch.manual_seed(0)
     model = model_create_by_name("psmnet", 192).cuda()
     for i in (1, 2, 3):
-        getattr(model, "classif%d" % i)[2].weight.data.mul_(1e-3)
+        with torch.no_grad():
+            getattr(model, "classif%d" % i)[2].weight.mul_(1e-3)
     lossfun = train.losses("supervised", model.count_levels, 0)
     lossfun.Weight_Adjust_levels(0)
     opt = train.make_optimizer(model, lr=1e-3)
@@ -76,7 +77,8 @@ def test_graphed_train_step_follows_the_eager_trajectory(hip_lib):
     torch.manual_seed(0)
     m1 = model_create_by_name("psmnet", 192).cuda()
     for i in (1, 2, 3):
-        getattr(m1, "classif%d" % i)[2].weight.data.mul_(1e-3)
+        with torch.no_grad():
+            getattr(m1, "classif%d" % i)[2].weight.mul_(1e-3)
     m2 = copy.deepcopy(m1)
     batches = [_batch(1, 256, 512, 6, s) for s in (5, 6, 7)]
     lf1, lf2 = train.losses("supervised", 1, 0), train.losses("supervised", 1, 0)
