@@ -304,13 +304,14 @@ def conv3d_out_size(in_size, stride, transposed):
 
 
 def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, stride=1,
-                 transposed=False, relu=False, out_size=None):
+                 transposed=False, relu=False, out_size=None, out="f32"):
     """y = relu?(conv(x) * scale + shift (+ residual, cropped to the common size)).
 
     ``x`` is (B,Cin,D,H,W); it is consumed in NDHWC memory (converted if needed) and
     the result is returned as a channels_last_3d tensor.  With ``residual`` the output
     takes the element-wise minimum of the two spatial sizes -- ``myadd_3d`` semantics
-    (stackhourglass.py:10-20).  Inference only (no autograd)."""
+    (stackhourglass.py:10-20).  ``out``: "f32" -> tensor; "s3" / "both" -> the result (also) as an
+    S3Volume for a following ``conv3d_s3_block`` (bf16x3 kernels only).  Inference only."""
     _require_device("conv3d_block", x, packed_weight, scale, shift, residual)
     x = to_channels_last_3d(x)
     B, cin, Di, Hi, Wi = x.shape
@@ -325,8 +326,15 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
         Do, Ho, Wo = min(Do, a.Dr), min(Ho, a.Hr), min(Wo, a.Wr)
     if out_size is not None:                     # a corner of the natural output (bwd-data crops)
         Do, Ho, Wo = (min(n, int(o)) for n, o in zip((Do, Ho, Wo), out_size))
-    y = torch.empty((B, cout, Do, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=_CL3D)
-    a.x, a.w_packed, a.y = x.data_ptr(), packed_weight.data_ptr(), y.data_ptr()
+    oshape = (B, cout, Do, Ho, Wo)
+    y = ys3 = None
+    if out in ("f32", "both"):
+        y = torch.empty(oshape, device=x.device, dtype=x.dtype, memory_format=_CL3D)
+    if out in ("s3", "both"):
+        ys3 = S3Volume(_s3_alloc(oshape, x.device), oshape)
+    a.x, a.w_packed = x.data_ptr(), packed_weight.data_ptr()
+    a.y = None if y is None else y.data_ptr()
+    a.y_s3 = None if ys3 is None else ys3.buf.data_ptr()
     a.scale = None if scale is None else scale.data_ptr()
     a.shift = None if shift is None else shift.data_ptr()
     a.residual = None if residual is None else residual.data_ptr()
@@ -342,7 +350,25 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     with torch.cuda.device(x.device), _timed(lambda: conv3d_plan_name(a), work):
         rc = _lib.load().dsm_conv3d_fwd(ctypes.byref(a), _stream())
     _lib.check(rc, "dsm_conv3d_fwd")
-    return y
+    if out == "f32":
+        return y
+    if out == "s3":
+        return ys3
+    return y, ys3
+
+
+def conv3d_supports_s3_out(cin, cout, stride, transposed):
+    """Layers whose kernel has the S3 epilogue: the bf16x3 3-D kernels (conv3d.hip make_plan)."""
+    if cout not in (32, 64):
+        return False
+    if transposed:
+        return cin % 32 == 0
+    return cin % 16 == 0 and get_option_bf16x3()
+
+
+def get_option_bf16x3():
+    import os
+    return not os.environ.get("DSM_CONV_PRECISION", "").startswith("f")
 
 
 def conv3d_plan_name(args):
@@ -350,6 +376,170 @@ def conv3d_plan_name(args):
     buf = ctypes.create_string_buffer(96)
     _lib.check(_lib.load().dsm_conv3d_plan(ctypes.byref(args), buf, 96), "dsm_conv3d_plan")
     return buf.value.decode()
+
+
+# ----------------------------------------------------------------------------
+# S3 activations (fp32 stored pre-split for the bf16 matrix pipe) and the z-sliding convolution
+# that consumes them -- csrc/conv_s3.hip, include/dsmnet_hip.h "S3"
+# ----------------------------------------------------------------------------
+_OPTIONS = {"s3": True, "fuse_volume": True}
+
+
+def set_option(name, value):
+    """Host-side switches for A/B runs and tests (no environment variable is read by the library):
+    ``s3`` -- eval-mode 32-channel stride-1 3-D layers run on the z-sliding S3 kernel;
+    ``fuse_volume`` -- PSMNet's eval forward never materialises the cost volume: the first 3-D
+    convolution stages it from the split feature maps."""
+    if name not in _OPTIONS:
+        raise KeyError(name)
+    old = _OPTIONS[name]
+    _OPTIONS[name] = bool(value)
+    return old
+
+
+def get_option(name):
+    return _OPTIONS[name]
+
+
+class S3Volume(object):
+    """A (B,C,D,H,W) fp32 activation held in the S3 format: ``buf`` is the raw byte buffer
+    (6 bytes per value), ``shape`` the logical shape.  ``to_tensor()`` returns the fp32 tensor
+    (channels_last_3d) it encodes, bit for bit."""
+    __slots__ = ("buf", "shape", "features")
+
+    def __init__(self, buf, shape, features=None):
+        self.buf, self.shape = buf, tuple(int(v) for v in shape)
+        self.features = features          # (fs, D, mask_left): a cost volume NOT materialised
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def to_tensor(self):
+        if self.features is not None:
+            raise RuntimeError("this S3Volume is a virtual cost volume (never materialised)")
+        B, C, D, H, W = self.shape
+        out = torch.empty(self.shape, device=self.buf.device, dtype=torch.float32, memory_format=_CL3D)
+        with torch.cuda.device(self.buf.device):
+            rc = _lib.load().dsm_s3_to_ndhwc(_p(self.buf), _p(out), B, C, D, H, W, _stream())
+        _lib.check(rc, "dsm_s3_to_ndhwc")
+        return out
+
+
+def _s3_alloc(shape, device):
+    B, C, D, H, W = shape
+    n = _lib.load().dsm_s3_bytes(B, C, D, H, W)
+    if n == 0:
+        raise ValueError("S3 needs C %% 32 == 0, got shape %s" % (tuple(shape),))
+    return torch.empty(n, device=device, dtype=torch.uint8)
+
+
+def s3_from_tensor(x):
+    """(B,C,D,H,W) fp32 -> S3Volume (lossless)."""
+    _require_device("s3_from_tensor", x)
+    x = to_channels_last_3d(x)
+    B, C, D, H, W = x.shape
+    buf = _s3_alloc(x.shape, x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().dsm_s3_from_ndhwc(_p(x), _p(buf), B, C, D, H, W, _stream())
+    _lib.check(rc, "dsm_s3_from_ndhwc")
+    return S3Volume(buf, x.shape)
+
+
+def concat_volume_s3(fL, fR, D, mask_left, materialise=True):
+    """The concatenation cost volume as an S3Volume (inference only).  ``materialise=False``:
+    only the split feature maps are made (a few MB) and the volume stays virtual -- the
+    z-sliding convolution stages plane d, row y straight from them (shift by d, mask x < d)."""
+    _require_device("concat_volume_s3", fL, fR)
+    _same_shape("concat_volume_s3", fL, fR)
+    fL, fR = fL.contiguous(), fR.contiguous()
+    B, C, H, W = fL.shape
+    lib = _lib.load()
+    nscr = lib.dsm_concat_volume_s3_scratch_bytes(B, C, H, W)
+    if nscr == 0:
+        raise ValueError("concat_volume_s3 needs C %% 32 == 0, got C = %d" % C)
+    fs = torch.empty(nscr, device=fL.device, dtype=torch.uint8)
+    shape = (B, 2 * C, int(D), H, W)
+    if not materialise:
+        with torch.cuda.device(fL.device), _timed("feat_s3_kernel", 4.0 * 2 * B * C * H * W + nscr):
+            rc = lib.dsm_features_s3(_p(fL), _p(fR), _p(fs), B, C, H, W, _stream())
+        _lib.check(rc, "dsm_features_s3")
+        return S3Volume(fs, shape, features=(int(D), int(bool(mask_left))))
+    vol = _s3_alloc(shape, fL.device)
+    # algorithmic bytes as SURVEY.md 8d counts the volume build (fp32): features read + volume written
+    with torch.cuda.device(fL.device), _timed("volume_s3_fwd_kernel", 4.0 * (2 * B * C * H * W + 2 * B * C * D * H * W)):
+        rc = lib.dsm_concat_volume_s3_fwd(_p(fL), _p(fR), _p(fs), _p(vol), B, C, H, W, int(D),
+                                          int(bool(mask_left)), _stream())
+    _lib.check(rc, "dsm_concat_volume_s3_fwd")
+    return S3Volume(vol, shape)
+
+
+def conv3d_s3_eligible(cin, cout, stride, transposed):
+    """Layers the z-sliding S3 kernel implements: Conv3d k3 s1 p1, Cin % 32 == 0 -> Cout = 32."""
+    return (not transposed) and stride == 1 and cout == 32 and cin % 32 == 0
+
+
+def pack_conv3d_s3_weight(weight):
+    _require_device("pack_conv3d_s3_weight", weight)
+    cout, cin = weight.shape[0], weight.shape[1]
+    lib = _lib.load()
+    n = lib.dsm_conv3d_s3_packed_weight_bytes(cin, cout)
+    if n == 0 or tuple(weight.shape[2:]) != (3, 3, 3):
+        raise ValueError("pack_conv3d_s3_weight: unsupported weight shape %s" % (tuple(weight.shape),))
+    w = weight.detach().contiguous()
+    packed = torch.empty(n, device=w.device, dtype=torch.uint8)
+    with torch.cuda.device(w.device):
+        rc = lib.dsm_conv3d_s3_pack_weights(_p(w), _p(packed), cin, cout, _stream())
+    _lib.check(rc, "dsm_conv3d_s3_pack_weights")
+    return packed
+
+
+def conv3d_s3_block(x, packed_weight, scale=None, shift=None, residual=None, relu=0, out="f32",
+                    grid=0):
+    """y = relu?(conv3d_k3s1p1(x) * scale + shift (+ residual, cropped)) with ``x`` an S3Volume and
+    32 output channels.  ``out``: "f32" -> tensor, "s3" -> S3Volume, "both" -> (tensor, S3Volume).
+    Inference only."""
+    if not isinstance(x, S3Volume):
+        raise TypeError("conv3d_s3_block takes an S3Volume")
+    _require_device("conv3d_s3_block", scale, shift, residual)
+    B, cin, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = Di, Hi, Wi
+    a = _lib.Conv3dS3Args()
+    if residual is not None:
+        if residual.shape[0] != B or residual.shape[1] != 32:
+            raise ValueError("conv3d_s3_block: residual has shape %s" % (tuple(residual.shape),))
+        residual = to_channels_last_3d(residual)
+        a.Dr, a.Hr, a.Wr = residual.shape[2:]
+        Do, Ho, Wo = min(Do, a.Dr), min(Ho, a.Hr), min(Wo, a.Wr)
+    oshape = (B, 32, Do, Ho, Wo)
+    y = ys3 = None
+    if out in ("f32", "both"):
+        y = torch.empty(oshape, device=x.device, dtype=torch.float32, memory_format=_CL3D)
+    if out in ("s3", "both"):
+        ys3 = S3Volume(_s3_alloc(oshape, x.device), oshape)
+    if y is None and ys3 is None:
+        raise ValueError("out must be 'f32', 's3' or 'both'")
+    a.x_s3, a.w_packed = x.buf.data_ptr(), packed_weight.data_ptr()
+    a.scale = None if scale is None else scale.data_ptr()
+    a.shift = None if shift is None else shift.data_ptr()
+    a.residual = None if residual is None else residual.data_ptr()
+    a.y = None if y is None else y.data_ptr()
+    a.y_s3 = None if ys3 is None else ys3.buf.data_ptr()
+    a.B, a.Cin, a.Cout = B, cin, 32
+    a.Di, a.Hi, a.Wi = Di, Hi, Wi
+    a.Do, a.Ho, a.Wo = Do, Ho, Wo
+    a.relu, a.grid = int(relu), int(grid)
+    if x.features is not None:
+        a.vol_virtual, a.vol_mask_left = 1, x.features[1]
+    work = 54.0 * cin * 32 * B * Do * Ho * Wo
+    with torch.cuda.device(x.device), _timed("conv3d_s3_bf16x3_mfma_kernel", work):
+        rc = _lib.load().dsm_conv3d_s3_fwd(ctypes.byref(a), _stream())
+    _lib.check(rc, "dsm_conv3d_s3_fwd")
+    if out == "f32":
+        return y
+    if out == "s3":
+        return ys3
+    return y, ys3
 
 
 # ----------------------------------------------------------------------------

@@ -101,6 +101,7 @@ template <int S, int KZ = 3, int KXY = 3, int DIL = 1> struct Geo {
 struct ConvParams {
   const float* x; const float* w; const float* scale; const float* shift;
   const float* res; float* y;
+  unsigned char* ys3;         // optional second output in the S3 format (conv_s3.hip); bf16x3 kernels only
   int B, Cin, Cout;
   int Di, Hi, Wi, Do, Ho, Wo, Dr, Hr, Wr;
   int relu;
@@ -166,6 +167,60 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const Affine& af, 
     if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     *reinterpret_cast<f32x4*>(yv + 8 * g) = v;
   }
+}
+
+// The same epilogue, the result also (or only) written in the S3 format of conv_s3.hip -- fp32
+// pre-split into three bf16 planes, [..][y][cg][plane][g][x][8] -- so that a z-sliding bf16x3
+// consumer needs no operand split.  Lane (r, h) of a 32x32 tile owns channels 8 q + 4 h + (0..3)
+// of its voxel (register quads q = 0..3), i.e. exactly the units g = h (quads 0, 2) and g = 2 + h
+// (quads 1, 3) of the voxel's 32-channel group: two 16-byte stores per plane.
+// `s3row`: the (voxel row, channel group) row-set, 12 rows of `Wo` units; `xo`: this lane's column.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned s3_pack_bf16(float a, float b) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const f2 t = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(t, b2));
+}
+__device__ __forceinline__ void s3_store_unit(const f32x4 lo4, const f32x4 hi4, unsigned char* o, long plane_stride) {
+  float r[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    unsigned u[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u[i] = s3_pack_bf16(r[2 * i], r[2 * i + 1]);
+      if (k < 2) {
+        r[2 * i] -= __builtin_bit_cast(float, u[i] << 16);
+        r[2 * i + 1] -= __builtin_bit_cast(float, u[i] & 0xffff0000u);
+      }
+    }
+    *reinterpret_cast<u32x4_t*>(o + k * plane_stride) = u32x4_t{u[0], u[1], u[2], u[3]};
+  }
+}
+template <int COUT>
+__device__ __forceinline__ void store_tile_s3(const f32x16& acc, const Affine& af, int relu,
+                                              float* __restrict__ yv, const float* __restrict__ rv,
+                                              unsigned char* __restrict__ s3row, int xo, int Wo, int h) {
+  f32x4 r4[4], v4[4];
+  if (rv) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) r4[g] = *reinterpret_cast<const f32x4*>(rv + 8 * g);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 sc = af.sc[g], sh = af.sh[g];
+    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    v = v * sc + sh;
+    if (relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (rv) v += r4[g];
+    if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (yv) *reinterpret_cast<f32x4*>(yv + 8 * g) = v;
+    v4[g] = v;
+  }
+  const long ps = 4l * Wo * 16;
+  s3_store_unit(v4[0], v4[2], s3row + ((long)h * Wo + xo) * 16, ps);
+  s3_store_unit(v4[1], v4[3], s3row + ((long)(2 + h) * Wo + xo) * 16, ps);
 }
 
 // ----------------------------------------------------------------------------
@@ -1106,7 +1161,7 @@ namespace {
 struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; int nsplit = 1; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1, 4 conv cout1 z-sliding, 5 conv bf16x3, 6 deconv bf16x3
 
 int make_plan(const dsm_conv3d_args* a, Plan* pl) {
-  DSM_REQUIRE(a && a->x && a->w_packed && a->y, DSM_ERR_ARG);
+  DSM_REQUIRE(a && a->x && a->w_packed && (a->y || a->y_s3), DSM_ERR_ARG);
   DSM_REQUIRE(a->B > 0 && a->Cin > 0 && a->Cout > 0, DSM_ERR_ARG);
   DSM_REQUIRE(a->Di > 0 && a->Hi > 0 && a->Wi > 0 && a->Do > 0 && a->Ho > 0 && a->Wo > 0,
               DSM_ERR_ARG);
@@ -1114,8 +1169,8 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   DSM_REQUIRE(!a->transposed || a->stride == 2, DSM_ERR_UNSUPPORTED);
   DSM_REQUIRE(a->relu >= 0 && a->relu <= 2, DSM_ERR_ARG);
   DSM_REQUIRE(a->Cin % 16 == 0, DSM_ERR_UNSUPPORTED);   // chunk sizes 8 and 16 both divide it
-  DSM_REQUIRE(dsm_aligned16(a->x) && dsm_aligned16(a->w_packed) && dsm_aligned16(a->y),
-              DSM_ERR_ALIGN);
+  DSM_REQUIRE(dsm_aligned16(a->x) && dsm_aligned16(a->w_packed) && dsm_aligned16(a->y) &&
+              dsm_aligned16(a->y_s3), DSM_ERR_ALIGN);
   const int kd = a->kd ? a->kd : 3, k = a->k ? a->k : 3, dil = a->dil ? a->dil : 1;
   DSM_REQUIRE((kd == 1 || kd == 3) && (k == 1 || k == 3) && (dil == 1 || dil == 2),
               DSM_ERR_UNSUPPORTED);
@@ -1224,9 +1279,12 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   Plan pl;
   int rc = make_plan(a, &pl);
   if (rc != DSM_OK) return rc;
+  // the S3 second output exists in the epilogue of the bf16x3 3-D kernels only
+  if (a->y_s3) DSM_REQUIRE((pl.kind == 5 || pl.kind == 6) && pl.KZ == 3, DSM_ERR_UNSUPPORTED);
   ConvParams p;
   p.x = (const float*)a->x; p.w = (const float*)a->w_packed; p.scale = a->scale;
   p.shift = a->shift; p.res = (const float*)a->residual; p.y = (float*)a->y;
+  p.ys3 = (unsigned char*)a->y_s3;
   p.B = a->B; p.Cin = a->Cin; p.Cout = a->Cout;
   p.Di = a->Di; p.Hi = a->Hi; p.Wi = a->Wi; p.Do = a->Do; p.Ho = a->Ho; p.Wo = a->Wo;
   p.Dr = a->Dr; p.Hr = a->Hr; p.Wr = a->Wr; p.relu = a->relu;

@@ -337,6 +337,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
           if (yo >= p.Ho || xo >= p.Wo) continue;
           const long vox = (((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo;
           const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
+          if (p.ys3)
+            store_tile_s3<COUT>(acc[m][n], af, p.relu, p.y ? p.y + vox * COUT + cbase : nullptr,
+                                p.res ? p.res + rvox * COUT + cbase : nullptr,
+                                p.ys3 + (((((long)tb * p.Do + tz) * p.Ho + yo) * NT + n) * 12) * p.Wo * 16,
+                                xo, p.Wo, h);
+          else
           store_tile<COUT>(acc[m][n], af, p.relu, p.y + vox * COUT + cbase,
                            p.res ? p.res + rvox * COUT + cbase : nullptr);
         }
@@ -564,6 +570,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void deconv_bf16x3_kernel(ConvParams p
             if (yo >= p.Ho || xo >= p.Wo) continue;
             const long vox = (((long)cur_pos.b * p.Do + zo) * p.Ho + yo) * p.Wo + xo;
             const long rvox = (((long)cur_pos.b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo;
+            if (p.ys3)
+              store_tile_s3<COUT>(acc[c][n], af, p.relu, p.y ? p.y + vox * COUT + cbase : nullptr,
+                                  p.res ? p.res + rvox * COUT + cbase : nullptr,
+                                  p.ys3 + (((((long)cur_pos.b * p.Do + zo) * p.Ho + yo) * NT + n) * 12) * p.Wo * 16,
+                                  xo, p.Wo, h);
+            else
             store_tile<COUT>(acc[c][n], af, p.relu, p.y + vox * COUT + cbase,
                              p.res ? p.res + rvox * COUT + cbase : nullptr);
           }

@@ -113,26 +113,29 @@ def _trunk_step_errors(seed, hw=(16, 40), d4=8):
     for a, b in zip(gc, costs):                                   # train-mode forward: tight
         assert maxerr(a, b) <= 2e-5 * b.abs().max().item()
     assert len(olog.masks) == len(glog.masks) == 21, (len(olog.masks), len(glog.masks))
-    flips = 0
+    flips = units = 0
     for a, b in zip(olog.masks, glog.masks):
         assert a.shape == b.shape
         flips += int((a != b).sum())
+        units += a.numel()
     params = dict(m.named_parameters())
     ggr = torch.autograd.grad(loss, [params[k] for k in keys] + [gfl, gfr])
     # running statistics were updated as nn.BatchNorm3d does
     assert maxerr(m.dres0[0][1].running_mean, osd["dres0.0.1.running_mean"]) <= 1e-4
     errs = {k: maxerr(g, r) / max(r.abs().max().item(), 1e-6)
             for k, g, r in zip(keys + ["fL", "fR"], ggr, ogr)}
-    return errs, flips
+    return errs, flips, units
 
 
-def _check_against_flips(errs, flips, nvox_min):
+def _check_against_flips(errs, flips, units, nvox_min):
     """No flipped unit: every gradient within 2e-3 (measured 3e-6).  Each flipped unit may move
     the gradients of a BatchNorm layer that sees ``nvox_min`` voxels per channel by ~1/nvox_min
-    (it changes one term of that channel's batch statistics); allow twice that per flip."""
+    (it changes one term of that channel's batch statistics); allow twice that per flip.
+    Rounding noise flips a ReLU input only when it lies within ~1e-6 of zero relative to the
+    layer's scale: at most a few per million units (measured 330 of 4.6e8 at the config #5 shape)."""
     worst = max(errs.values())
     bound = 2e-3 + flips * 2.0 / nvox_min
-    assert flips <= 16, "too many sign flips (%d) for rounding noise: %r" % (flips, errs)
+    assert flips <= 16 + 3e-6 * units, "too many sign flips (%d of %d) for rounding noise: %r" % (flips, units, errs)
     assert worst <= bound, "flips=%d bound=%.3e: %r" % (flips, bound, errs)
 
 
@@ -147,8 +150,8 @@ def test_psmnet_trunk_training_step_vs_oracle(hip_lib):
     implementations) and bounds each seed's error by what that many flips can explain; a seed
     without flips must agree to 2e-3.  The smallest BN layer here sees 2x4x10 = 80 voxels."""
     for seed in (81, 71, 101):
-        errs, flips = _trunk_step_errors(seed)
-        _check_against_flips(errs, flips, 80)
+        errs, flips, units = _trunk_step_errors(seed)
+        _check_against_flips(errs, flips, units, 80)
 
 
 def test_psmnet_trunk_training_step_at_config5_shape(hip_lib):
@@ -156,8 +159,8 @@ def test_psmnet_trunk_training_step_at_config5_shape(hip_lib):
     (540x960, D=192).  The odd sizes exercise the crop of ``myadd_3d`` on every level
     (135 -> 68 -> 34 -> 68 -> 136 vs 135; stackhourglass.py:10-20) in forward AND backward.
     Gradients against the oracle's CPU autograd, bounded by the counted ReLU sign flips."""
-    errs, flips = _trunk_step_errors(91, hw=(135, 240), d4=48)
-    _check_against_flips(errs, flips, 12 * 34 * 60)
+    errs, flips, units = _trunk_step_errors(91, hw=(135, 240), d4=48)
+    _check_against_flips(errs, flips, units, 12 * 34 * 60)
 
 
 def test_psmnet_full_training_step(hip_lib):
