@@ -16,7 +16,7 @@ SOURCES = ["abi.hip", "corr1d.hip", "cost_volume.hip", "soft_argmin.hip", "conv3
 LIB = os.path.join(HERE, "libdsmnet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("HIPCC_EXTRA", "").split()
 
 
 def _stale(out, deps):

@@ -2,7 +2,7 @@
 the rocprofv3 --pmc passes (profiles/) and of quick A/B timing.
 
     python3 scripts/bench_kernels.py [kernel ...] [--iters N]
-kernels: volume volume_ncdhw conv32 conv64in conv_l1 conv_s2 deconv6 deconv5 cout1 softargmin corr
+kernels: s3conv32 s3conv64in s3conv64virt volume_s3 volume volume_ncdhw conv32 conv64in conv_l1 conv_s2 deconv6 deconv5 cout1 softargmin corr
 """
 import argparse
 import sys
@@ -19,6 +19,9 @@ args = ap.parse_args()
 dev = "cuda"
 torch.manual_seed(0)
 CL = torch.channels_last_3d
+
+
+L0, L1, L2 = (48, 96, 320), (24, 48, 160), (12, 24, 80)
 
 
 def vol(c, d, h, w):
@@ -39,11 +42,29 @@ def conv_case(cin, cout, dims, stride=1, transposed=False, relu=1, res=False):
     return (lambda: cv.conv3d_block(x, packed, cout, sc, sh, r, stride, transposed, relu)), flops, "FLOP"
 
 
+def s3_case(cin, dims, virtual=False, out="both", res=True):
+    w = torch.randn(32, cin, 3, 3, 3, device=dev) * (2.0 / (27 * 32)) ** 0.5
+    packed = cv.pack_conv3d_s3_weight(w)
+    sc, sh = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
+    if virtual:
+        a, b = torch.randn(1, cin // 2, *dims[1:], device=dev), torch.randn(1, cin // 2, *dims[1:], device=dev)
+        xs = cv.concat_volume_s3(a, b, dims[0], True, materialise=False)
+    else:
+        xs = cv.s3_from_tensor(vol(cin, *dims))
+    r = vol(32, *dims) if res else None
+    flops = 54.0 * cin * 32 * dims[0] * dims[1] * dims[2]
+    return (lambda: cv.conv3d_s3_block(xs, packed, sc, sh, r, relu=1, out=out)), flops, "FLOP"
+
+
 fl, fr = torch.randn(1, 32, 96, 320, device=dev), torch.randn(1, 32, 96, 320, device=dev)
 cost = torch.randn(1, 1, 48, 96, 320, device=dev) * 2
 cl, cr = torch.randn(1, 128, 96, 320, device=dev), torch.randn(1, 128, 96, 320, device=dev)
-L0, L1, L2 = (48, 96, 320), (24, 48, 160), (12, 24, 80)
 CASES = {
+    "s3conv32": lambda: s3_case(32, L0),
+    "s3conv32_f32out": lambda: s3_case(32, L0, out="f32", res=False),
+    "s3conv64in": lambda: s3_case(64, L0, out="s3", res=False),
+    "s3conv64virt": lambda: s3_case(64, L0, virtual=True, out="s3", res=False),
+    "volume_s3": lambda: ((lambda: cv.concat_volume_s3(fl, fr, 48, True)), 385351680.0, "B"),
     "volume": lambda: ((lambda: cv.concat_volume(fl, fr, 48, True, True)), 385351680.0, "B"),
     "volume_ncdhw": lambda: ((lambda: cv.concat_volume(fl, fr, 48, True, False)), 385351680.0, "B"),
     "conv32": lambda: conv_case(32, 32, L0),
