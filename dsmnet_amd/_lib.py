@@ -37,7 +37,8 @@ class Conv3dArgs(ctypes.Structure):
                 ("Do", c_int), ("Ho", c_int), ("Wo", c_int),
                 ("Dr", c_int), ("Hr", c_int), ("Wr", c_int),
                 ("stride", c_int), ("transposed", c_int), ("relu", c_int),
-                ("kd", c_int), ("k", c_int), ("dil", c_int), ("y_s3", c_void_p)]
+                ("kd", c_int), ("k", c_int), ("dil", c_int), ("y_s3", c_void_p),
+                ("x_s3", c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in dsmnet_hip.h
@@ -53,6 +54,7 @@ SIGNATURES = {
     "dsm_conv3d_packed_weight_bytes": (c_size_t, [c_int] * 3),
     "dsm_conv3d_pack_weights": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "dsm_conv_pack_weights": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
+    "dsm_conv_pack_weights_s3in": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "dsm_conv3d_fwd": (c_int, [ctypes.POINTER(Conv3dArgs), c_void_p]),
     "dsm_conv3d_plan": (c_int, [ctypes.POINTER(Conv3dArgs), ctypes.c_char_p, c_int]),
     "dsm_conv3d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),

@@ -40,6 +40,7 @@ class _Folded(object):
         self.key = None
         self.packed = self.scale = self.shift = None
         self.packed_s3 = None            # packing for the z-sliding S3 kernel, made on first use
+        self.packed_s3in = None          # packing for a bf16x3 launch that reads an S3 input
 
     def get(self, conv, bn):
         transposed = isinstance(conv, nn.ConvTranspose3d)
@@ -66,8 +67,16 @@ class _Folded(object):
                 else:
                     self.scale = self.shift = None
             self.key = key
-            self.packed_s3 = None
+            self.packed_s3 = self.packed_s3in = None
         return self.packed, self.scale, self.shift
+
+    def get_s3in(self, conv, bn):
+        """(weights packed for a bf16x3 launch with an S3 input, scale, shift)."""
+        _, scale, shift = self.get(conv, bn)
+        if self.packed_s3in is None:
+            with torch.no_grad():
+                self.packed_s3in = cv.pack_conv_weight_s3in(conv.weight)
+        return self.packed_s3in, scale, shift
 
     def get_s3(self, conv, bn):
         """(weights packed for ``conv3d_s3_block``, scale, shift)."""
@@ -121,6 +130,17 @@ def _s3_layer(conv):
             cv.conv3d_s3_eligible(conv.in_channels, conv.out_channels, conv.stride[0], False))
 
 
+def _s3in_layer(conv):
+    """Can this layer's bf16x3 kernel read an S3 input?"""
+    return (cv.get_option("s3") and isinstance(conv, nn.Conv3d) and
+            cv.conv_s3in_eligible(conv.in_channels, conv.out_channels, conv.stride[0], False))
+
+
+def takes_s3(conv):
+    """An S3 input is worth making for this layer (either S3 path applies)."""
+    return _s3_layer(conv) or _s3in_layer(conv)
+
+
 def _fast_eval(conv, bn, x):
     """Eval-mode, no autograd: the fused single-launch kernels apply."""
     if bn is not None and bn.training:
@@ -158,6 +178,10 @@ def run_block(folded, conv, bn, x, residual=None, relu=RELU_NONE, out="f32"):
         if _s3_layer(conv):
             packed, scale, shift = folded.get_s3(conv, bn)
             return cv.conv3d_s3_block(x, packed, scale, shift, residual, relu=relu, out=out)
+        if _s3in_layer(conv) and x.features is None:
+            packed, scale, shift = folded.get_s3in(conv, bn)
+            return cv.conv3d_block(x, packed, conv.out_channels, scale, shift, residual,
+                                   stride=conv.stride[0], transposed=False, relu=relu, out=out)
         x = x.to_tensor()                      # a consumer without an S3 path (not a reference pattern)
     packed, scale, shift = folded.get(conv, bn)
     if out != "f32" and not cv.conv3d_supports_s3_out(conv.in_channels, conv.out_channels,
@@ -202,7 +226,7 @@ class ConvBN3d(nn.Sequential):
         return run_block(self._folded, conv, bn, x, residual, mode, out)
 
     def eats_s3(self):
-        return _s3_layer(self[0])
+        return takes_s3(self[0])
 
 
 class Chain3d(nn.Sequential):
@@ -233,7 +257,7 @@ class Chain3d(nn.Sequential):
             else:
                 nxt = mods[convs[convs.index(i) + 1]]
                 nconv = nxt[0] if isinstance(nxt, ConvBN3d) else nxt
-                fmt = "s3" if (_s3_layer(nconv) and self._eval_no_grad(m, x)) else "f32"
+                fmt = "s3" if (takes_s3(nconv) and self._eval_no_grad(m, x)) else "f32"
             if isinstance(m, ConvBN3d):
                 if res is not None and nxt_relu:
                     raise ValueError("skip-add before an inner ReLU is not a reference pattern")
@@ -258,7 +282,7 @@ class Chain3d(nn.Sequential):
 
     def eats_s3(self):
         m = next(m for m in self if isinstance(m, (ConvBN3d, nn.Conv3d, nn.ConvTranspose3d)))
-        return _s3_layer(m[0] if isinstance(m, ConvBN3d) else m)
+        return takes_s3(m[0] if isinstance(m, ConvBN3d) else m)
 
 
 class Conv3dHip(nn.Conv3d):

@@ -312,8 +312,12 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     takes the element-wise minimum of the two spatial sizes -- ``myadd_3d`` semantics
     (stackhourglass.py:10-20).  ``out``: "f32" -> tensor; "s3" / "both" -> the result (also) as an
     S3Volume for a following ``conv3d_s3_block`` (bf16x3 kernels only).  Inference only."""
-    _require_device("conv3d_block", x, packed_weight, scale, shift, residual)
-    x = to_channels_last_3d(x)
+    xs3 = x if isinstance(x, S3Volume) else None
+    _require_device("conv3d_block", None if xs3 else x, scale, shift, residual)
+    if xs3 is None:
+        x = to_channels_last_3d(x)
+    elif xs3.features is not None:
+        raise ValueError("conv3d_block cannot read a virtual cost volume")
     B, cin, Di, Hi, Wi = x.shape
     Do, Ho, Wo = conv3d_out_size((Di, Hi, Wi), stride, transposed)
     a = _lib.Conv3dArgs()
@@ -329,10 +333,14 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     oshape = (B, cout, Do, Ho, Wo)
     y = ys3 = None
     if out in ("f32", "both"):
-        y = torch.empty(oshape, device=x.device, dtype=x.dtype, memory_format=_CL3D)
+        y = torch.empty(oshape, device=x.device, dtype=torch.float32, memory_format=_CL3D)
     if out in ("s3", "both"):
         ys3 = S3Volume(_s3_alloc(oshape, x.device), oshape)
-    a.x, a.w_packed = x.data_ptr(), packed_weight.data_ptr()
+    if xs3 is None:
+        a.x = x.data_ptr()
+    else:
+        a.x_s3 = xs3.buf.data_ptr()           # packed_weight must come from pack_conv_weight_s3in
+    a.w_packed = packed_weight.data_ptr()
     a.y = None if y is None else y.data_ptr()
     a.y_s3 = None if ys3 is None else ys3.buf.data_ptr()
     a.scale = None if scale is None else scale.data_ptr()
@@ -369,6 +377,34 @@ def conv3d_supports_s3_out(cin, cout, stride, transposed):
 def get_option_bf16x3():
     import os
     return not os.environ.get("DSM_CONV_PRECISION", "").startswith("f")
+
+
+def conv_s3in_eligible(cin, cout, stride, transposed, kd=3, k=3, dil=1):
+    """Layers whose bf16x3 convolution kernel can read an S3 input (conv3d.hip make_plan +
+    the variants compiled there): 3x3(x3), not transposed, Cin % 32 == 0."""
+    if transposed or k != 3 or cin % 32 != 0 or not get_option_bf16x3():
+        return False
+    if kd == 3:
+        return dil == 1 and ((stride == 1 and cout in (32, 64)) or (stride == 2 and cout == 64))
+    return stride == 1 and ((dil == 1 and cout in (32, 64, 128)) or (dil == 2 and cout == 128))
+
+
+def pack_conv_weight_s3in(weight):
+    """torch Conv3d / Conv2d weight (k = 3) -> the packed buffer of a launch that reads an S3 input
+    (the bf16x3 section in the k-slot order of the S3 units)."""
+    _require_device("pack_conv_weight_s3in", weight)
+    kd = 3 if weight.dim() == 5 else 1
+    cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[-1]
+    w = weight.detach().contiguous()
+    lib = _lib.load()
+    nbytes = lib.dsm_conv_packed_weight_bytes(cin, cout, kd, k)
+    if nbytes == 0:
+        raise ValueError("pack_conv_weight_s3in: unsupported shape %s" % (tuple(weight.shape),))
+    packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        rc = lib.dsm_conv_pack_weights_s3in(_p(w), _p(packed), cin, cout, kd, k, _stream())
+    _lib.check(rc, "dsm_conv_pack_weights_s3in")
+    return packed
 
 
 def conv3d_plan_name(args):
@@ -569,13 +605,19 @@ def pack_conv2d_weight(weight, cin_padded=None):
 
 
 def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, stride=1,
-                 relu=0, k=3, dilation=1):
+                 relu=0, k=3, dilation=1, out="f32"):
     """y = relu?(conv2d(x) * scale + shift (+ residual)) on NHWC maps, "same" padding.
-    ``x``: (B, Cin, H, W) in torch.channels_last memory, Cin a multiple of 16.  Inference only."""
-    _require_device("conv2d_block", x, packed_weight, scale, shift, residual)
-    if not x.is_contiguous(memory_format=_CL2D):
-        x = x.contiguous(memory_format=_CL2D)
-    B, cin, Hi, Wi = x.shape
+    ``x``: (B, Cin, H, W) in torch.channels_last memory, Cin a multiple of 16 -- or the map as an
+    ``S3Volume`` of shape (B, Cin, 1, H, W) (weights then from ``pack_conv_weight_s3in``).
+    ``out``: "f32" -> tensor; "s3" / "both" -> (also) an S3Volume (bf16x3 kernels).  Inference only."""
+    xs3 = x if isinstance(x, S3Volume) else None
+    _require_device("conv2d_block", None if xs3 else x, packed_weight, scale, shift, residual)
+    if xs3 is None:
+        if not x.is_contiguous(memory_format=_CL2D):
+            x = x.contiguous(memory_format=_CL2D)
+        B, cin, Hi, Wi = x.shape
+    else:
+        B, cin, _, Hi, Wi = xs3.shape
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
     a = _lib.Conv3dArgs()
     if residual is not None:
@@ -585,8 +627,19 @@ def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
         if not residual.is_contiguous(memory_format=_CL2D):
             residual = residual.contiguous(memory_format=_CL2D)
         a.Dr, a.Hr, a.Wr = 1, Ho, Wo
-    y = torch.empty((B, cout, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=_CL2D)
-    a.x, a.w_packed, a.y = x.data_ptr(), packed_weight.data_ptr(), y.data_ptr()
+    dev = packed_weight.device
+    y = ys3 = None
+    if out in ("f32", "both"):
+        y = torch.empty((B, cout, Ho, Wo), device=dev, dtype=torch.float32, memory_format=_CL2D)
+    if out in ("s3", "both"):
+        ys3 = S3Volume(_s3_alloc((B, cout, 1, Ho, Wo), dev), (B, cout, 1, Ho, Wo))
+    if xs3 is None:
+        a.x = x.data_ptr()
+    else:
+        a.x_s3 = xs3.buf.data_ptr()
+    a.w_packed = packed_weight.data_ptr()
+    a.y = None if y is None else y.data_ptr()
+    a.y_s3 = None if ys3 is None else ys3.buf.data_ptr()
     a.scale = None if scale is None else scale.data_ptr()
     a.shift = None if shift is None else shift.data_ptr()
     a.residual = None if residual is None else residual.data_ptr()
@@ -596,10 +649,14 @@ def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     a.stride, a.transposed, a.relu = int(stride), 0, int(relu)
     a.kd, a.k, a.dil = 1, int(k), int(dilation)
     work = 2.0 * k * k * cin * cout * B * Ho * Wo
-    with torch.cuda.device(x.device), _timed(lambda: conv3d_plan_name(a), work):
+    with torch.cuda.device(dev), _timed(lambda: conv3d_plan_name(a), work):
         rc = _lib.load().dsm_conv3d_fwd(ctypes.byref(a), _stream())
     _lib.check(rc, "dsm_conv3d_fwd")
-    return y
+    if out == "f32":
+        return y
+    if out == "s3":
+        return ys3
+    return y, ys3
 
 
 def warp_abs_error(left, right, disp, delt):

@@ -1056,7 +1056,7 @@ int run_conv(ConvParams p, hipStream_t s, int nsplit = 1) {
   return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK, KZ, KXY, DIL>, p, lds, s, 512 / nsplit, nsplit);
 }
 
-template <int NT, int TM, int KZ, int DIL, int S = 1>
+template <int NT, int TM, int KZ, int DIL, int S = 1, bool S3IN = false>
 int run_conv_bf16x3(ConvParams p, hipStream_t s) {
   constexpr int TY = 4 * TM, IY = (TY - 1) * S + 2 * DIL + 1, IX = 31 * S + 2 * DIL + 1;
   constexpr int NPF = (IY * IX * 4 + NTHREADS - 1) / NTHREADS;
@@ -1065,9 +1065,10 @@ int run_conv_bf16x3(ConvParams p, hipStream_t s) {
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
   // two images, one workgroup per CU
-  const size_t lds = ((S == 1) ? (size_t)2 * NPF * 64 * 112 : (size_t)2 * (IY * 66 + 4) * 112) +
+  const size_t lds = ((S == 1 && !S3IN) ? (size_t)2 * NPF * 64 * 112
+                                       : (size_t)2 * (IY * (S == 1 ? IX : 66) + 4) * 112) +
                      2 * 32 * NT * sizeof(float);                    // + scale / shift
-  return launch_tiles(conv_bf16x3_kernel<NT, TM, KZ, DIL, S>, p, lds, s, 256);
+  return launch_tiles(conv_bf16x3_kernel<NT, TM, KZ, DIL, S, S3IN>, p, lds, s, 256);
 }
 
 template <int NT>
@@ -1127,12 +1128,12 @@ extern "C" int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed, int 
   if (bf16x3_section_bytes(Cin, Cout, 3, 3))
     hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float*)w_torch,
-                       (unsigned short*)((float*)w_packed + n), Cin, Cout, transposed, 27, Cin);
+                       (unsigned short*)((float*)w_packed + n), Cin, Cout, transposed, 27, Cin, 0);
   return dsm_launch_status();
 }
 
-extern "C" int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, int Cin,
-                                     int Cout, int kd, int k, dsm_stream_t stream) {
+static int conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, int Cin,
+                             int Cout, int kd, int k, int s3order, dsm_stream_t stream) {
   DSM_REQUIRE(w_torch && w_packed && w_torch != w_packed, DSM_ERR_ARG);
   DSM_REQUIRE(Cin_src > 0 && Cin >= Cin_src && Cout > 0, DSM_ERR_ARG);
   DSM_REQUIRE((kd == 1 || kd == 3) && (k == 1 || k == 3), DSM_ERR_UNSUPPORTED);
@@ -1146,8 +1147,22 @@ extern "C" int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Ci
   if (bf16x3_section_bytes(Cin, Cout, kd, k))
     hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float*)w_torch,
-                       (unsigned short*)((float*)w_packed + n), Cin, Cout, 0, ntaps, Cin_src);
+                       (unsigned short*)((float*)w_packed + n), Cin, Cout, 0, ntaps, Cin_src, s3order);
   return dsm_launch_status();
+}
+
+extern "C" int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, int Cin,
+                                     int Cout, int kd, int k, dsm_stream_t stream) {
+  return conv_pack_weights(w_torch, w_packed, Cin_src, Cin, Cout, kd, k, 0, stream);
+}
+
+// The same buffer with the bf16x3 section in the k-slot order of an S3-input launch
+// (dsm_conv3d_args.x_s3): 3x3(x3) kernels, Cin % 32 == 0.
+extern "C" int dsm_conv_pack_weights_s3in(const void* w_torch, void* w_packed, int Cin, int Cout,
+                                          int kd, int k, dsm_stream_t stream) {
+  DSM_REQUIRE(Cin > 0 && Cin % 32 == 0 && k == 3, DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(bf16x3_section_bytes(Cin, Cout, kd, k) != 0, DSM_ERR_UNSUPPORTED);
+  return conv_pack_weights(w_torch, w_packed, Cin, Cin, Cout, kd, k, 1, stream);
 }
 
 extern "C" size_t dsm_conv_packed_weight_bytes(int Cin, int Cout, int kd, int k) {
@@ -1161,7 +1176,7 @@ namespace {
 struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; int nsplit = 1; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1, 4 conv cout1 z-sliding, 5 conv bf16x3, 6 deconv bf16x3
 
 int make_plan(const dsm_conv3d_args* a, Plan* pl) {
-  DSM_REQUIRE(a && a->x && a->w_packed && (a->y || a->y_s3), DSM_ERR_ARG);
+  DSM_REQUIRE(a && (a->x || a->x_s3) && !(a->x && a->x_s3) && a->w_packed && (a->y || a->y_s3), DSM_ERR_ARG);
   DSM_REQUIRE(a->B > 0 && a->Cin > 0 && a->Cout > 0, DSM_ERR_ARG);
   DSM_REQUIRE(a->Di > 0 && a->Hi > 0 && a->Wi > 0 && a->Do > 0 && a->Ho > 0 && a->Wo > 0,
               DSM_ERR_ARG);
@@ -1169,8 +1184,9 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   DSM_REQUIRE(!a->transposed || a->stride == 2, DSM_ERR_UNSUPPORTED);
   DSM_REQUIRE(a->relu >= 0 && a->relu <= 2, DSM_ERR_ARG);
   DSM_REQUIRE(a->Cin % 16 == 0, DSM_ERR_UNSUPPORTED);   // chunk sizes 8 and 16 both divide it
-  DSM_REQUIRE(dsm_aligned16(a->x) && dsm_aligned16(a->w_packed) && dsm_aligned16(a->y) &&
-              dsm_aligned16(a->y_s3), DSM_ERR_ALIGN);
+  DSM_REQUIRE(dsm_aligned16(a->x) && dsm_aligned16(a->x_s3) && dsm_aligned16(a->w_packed) &&
+              dsm_aligned16(a->y) && dsm_aligned16(a->y_s3), DSM_ERR_ALIGN);
+  if (a->x_s3) DSM_REQUIRE(a->Cin % 32 == 0, DSM_ERR_UNSUPPORTED);
   const int kd = a->kd ? a->kd : 3, k = a->k ? a->k : 3, dil = a->dil ? a->dil : 1;
   DSM_REQUIRE((kd == 1 || kd == 3) && (k == 1 || k == 3) && (dil == 1 || dil == 2),
               DSM_ERR_UNSUPPORTED);
@@ -1265,9 +1281,9 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
     case 2: snprintf(buf, len, "conv3d_cout1_kernel<CK=%d>", pl.CK); break;
     case 4: snprintf(buf, len, "conv3d_cout1_zslide_kernel"); break;
     case 5:
-      if (pl.KZ == 3 && pl.S == 2) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<S=2,NT=%d,TM=%d>", pl.NT, pl.TM);
-      else if (pl.KZ == 3) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>", pl.NT, pl.TM);
-      else snprintf(buf, len, "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>", pl.NT, pl.TM, pl.DIL);
+      if (pl.KZ == 3 && pl.S == 2) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<S=2,NT=%d,TM=%d%s>", pl.NT, pl.TM, a->x_s3 ? ",S3IN" : "");
+      else if (pl.KZ == 3) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d%s>", pl.NT, pl.TM, a->x_s3 ? ",S3IN" : "");
+      else snprintf(buf, len, "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d%s>", pl.NT, pl.TM, pl.DIL, a->x_s3 ? ",S3IN" : "");
       break;
     case 6: snprintf(buf, len, "deconv3d_bf16x3_mfma_kernel<NT=%d>", pl.NT); break;
     default: snprintf(buf, len, "deconv3d_cout1_kernel"); break;
@@ -1279,10 +1295,12 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   Plan pl;
   int rc = make_plan(a, &pl);
   if (rc != DSM_OK) return rc;
-  // the S3 second output exists in the epilogue of the bf16x3 3-D kernels only
-  if (a->y_s3) DSM_REQUIRE((pl.kind == 5 || pl.kind == 6) && pl.KZ == 3, DSM_ERR_UNSUPPORTED);
+  // the S3 second output exists in the epilogue of the bf16x3 kernels only; an S3 input is
+  // understood by the bf16x3 convolution (not the transposed one) only
+  if (a->y_s3) DSM_REQUIRE(pl.kind == 5 || pl.kind == 6, DSM_ERR_UNSUPPORTED);
+  if (a->x_s3) DSM_REQUIRE(pl.kind == 5, DSM_ERR_UNSUPPORTED);
   ConvParams p;
-  p.x = (const float*)a->x; p.w = (const float*)a->w_packed; p.scale = a->scale;
+  p.x = a->x_s3 ? (const float*)a->x_s3 : (const float*)a->x; p.w = (const float*)a->w_packed; p.scale = a->scale;
   p.shift = a->shift; p.res = (const float*)a->residual; p.y = (float*)a->y;
   p.ys3 = (unsigned char*)a->y_s3;
   p.B = a->B; p.Cin = a->Cin; p.Cout = a->Cout;
@@ -1290,7 +1308,8 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   p.Dr = a->Dr; p.Hr = a->Hr; p.Wr = a->Wr; p.relu = a->relu;
   p.ntx = p.nty = p.ntiles = 0;
   {
-    const unsigned long xb = 4ul * a->B * a->Di * a->Hi * a->Wi * a->Cin;
+    const unsigned long xb = (a->x_s3 ? 6ul : 4ul) * a->B * a->Di * a->Hi * a->Wi * a->Cin;
+    if (a->x_s3) DSM_REQUIRE(xb < (1ul << 31), DSM_ERR_UNSUPPORTED);          // the out-of-range marker must lie past the tensor
     const int kd_ = a->kd ? a->kd : 3, k_ = a->k ? a->k : 3;
     const unsigned long wb = 4ul * a->Cin * a->Cout * kd_ * k_ * k_;
     DSM_REQUIRE(xb < (1ul << 32) && wb < (1ul << 32), DSM_ERR_UNSUPPORTED);   // 32-bit buffer offsets
@@ -1314,10 +1333,10 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   if (pl.kind == 5) {
     p.w = (const float*)a->w_packed + (size_t)a->Cin * a->Cout * pl.KZ * 9;   // section 2
     p.wbytes = (unsigned)bf16x3_section_bytes(a->Cin, a->Cout, pl.KZ, 3);
-    if (pl.S == 2) return run_conv_bf16x3<2, 1, 3, 1, 2>(p, s);
+    if (pl.S == 2) return a->x_s3 ? run_conv_bf16x3<2, 1, 3, 1, 2, true>(p, s) : run_conv_bf16x3<2, 1, 3, 1, 2>(p, s);
 #define DSM_CASE_BF(NT_, TM_, KZ_, DIL_) \
     if (pl.NT == NT_ && pl.TM == TM_ && pl.KZ == KZ_ && pl.DIL == DIL_) \
-      return run_conv_bf16x3<NT_, TM_, KZ_, DIL_>(p, s)
+      return a->x_s3 ? run_conv_bf16x3<NT_, TM_, KZ_, DIL_, 1, true>(p, s) : run_conv_bf16x3<NT_, TM_, KZ_, DIL_>(p, s)
     DSM_CASE_BF(1, 4, 3, 1); DSM_CASE_BF(1, 2, 3, 1); DSM_CASE_BF(2, 2, 3, 1);
     DSM_CASE_BF(1, 4, 1, 1); DSM_CASE_BF(1, 2, 1, 1); DSM_CASE_BF(2, 2, 1, 1); DSM_CASE_BF(4, 2, 1, 1);
     DSM_CASE_BF(4, 2, 1, 2);

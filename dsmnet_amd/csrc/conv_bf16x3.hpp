@@ -80,27 +80,37 @@ __device__ __forceinline__ Affine load_affine_lds(const float* aff, int cout, in
 // S = 2 (stride 2, DIL = 1, KZ = 3): the halo box is (2 TY + 1) x 65 voxels; its LDS image keeps
 // even and odd columns of a row apart (row pitch 66 voxels: 33 even, 33 odd) so that the lanes of
 // a fragment read, which step two input columns, stay 112 B apart.
-template <int NT, int TM, int KZ, int DIL, int S = 1>
+// S3IN: the input arrives in the S3 format of conv_s3.hip (fp32 pre-split into three bf16 planes by
+// the layer that produced it): staging is a 16-byte copy, six per voxel and chunk (3 planes x 2
+// units), and the operand split -- 16 % of this kernel's time by ablation, plus the bank conflicts
+// of its ds_write_b64 -- is gone from the MFMA stream.  A chunk of 16 k-slots is then units
+// 2 (ck & 1), 2 (ck & 1) + 1 of channel group ck / 2: k-slot j of lane half h is channel
+// 32 (ck / 2) + 16 (j / 4) + 4 (2 (ck & 1) + h) + (j & 3); the weights are packed in that order
+// (dsm_conv_pack_weights_s3in).
+template <int NT, int TM, int KZ, int DIL, int S = 1, bool S3IN = false>
 __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) {
   static_assert(S == 1 || (S == 2 && DIL == 1 && KZ == 3), "stride 2: 3x3x3, no dilation");
-  constexpr int TY = 4 * TM, NQ = 4, CK = 16;
+  constexpr int TY = 4 * TM, NQ = S3IN ? 6 : 4, CK = 16;
   constexpr int IY = (TY - 1) * S + 2 * DIL + 1, IX = 31 * S + 2 * DIL + 1;
   constexpr int NVOX = IY * IX;
-  constexpr int NE = NVOX * NQ;                 // staged 16-B fp32 quads per chunk
+  constexpr int NE = NVOX * NQ;                 // staged 16-B elements per chunk (fp32 quads, or S3 units)
   constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
   constexpr int PITCH = 112;                    // bytes per voxel in LDS: 3 planes x 32 B + 16 pad
   constexpr int RP = (S == 1) ? IX : 66;        // voxels per image row
-  constexpr int IMG = (S == 1) ? NPF * 64 * PITCH : (IY * RP + 4) * PITCH;   // (S = 1: the tail quads land in padding)
+  constexpr int IMG = (S == 1 && !S3IN) ? NPF * 64 * PITCH : (IY * RP + 4) * PITCH;   // (fp32, S = 1: the tail quads land in padding)
   constexpr int NITEM = 9;
   constexpr int NGROUP = NITEM * TM;            // (tap, row) groups of 6 NT MFMAs per chunk
   constexpr int AHEAD = 3;                      // weight ring: two items ahead (eight measured the same, twice)
-  // staging schedule.  S = 1: one load per group over the first NPF groups, half an element
-  // split per group over the last 2 NPF.  S = 2 (ten elements for nine groups): every load in
-  // group 0, four halves per group from group 4.
-  constexpr int LPG = (S == 1) ? 1 : NPF;                       // loads per group
-  constexpr int CONV0 = (S == 1) ? NGROUP - 2 * NPF : 4;        // first group that converts
-  constexpr int CPG = (2 * NPF + (NGROUP - CONV0) - 1) / (NGROUP - CONV0);   // halves per group
+  // staging schedule.  fp32 input, S = 1: one load per group over the first NPF groups, half an
+  // element split per group over the last 2 NPF.  S = 2 (ten elements for nine groups): every load
+  // in group 0, four halves per group from group 4.  S3 input: LPG loads per group from group 0,
+  // the same number of 16-byte stores per group over the last groups.
+  constexpr int LPG = S3IN ? (NPF + NGROUP / 2 - 1) / (NGROUP / 2) : ((S == 1) ? 1 : NPF);   // loads per group
+  constexpr int CONV0 = S3IN ? NGROUP - (NPF + LPG - 1) / LPG
+                             : ((S == 1) ? NGROUP - 2 * NPF : 4);   // first group that converts / stores
+  constexpr int CPG = S3IN ? LPG : (2 * NPF + (NGROUP - CONV0) - 1) / (NGROUP - CONV0);   // halves (stores) per group
   static_assert(NPF <= NGROUP * LPG && CONV0 >= 2, "staging schedule");
+  static_assert(!S3IN || CONV0 > (NPF + LPG - 1) / LPG, "a store must come after its load");
   constexpr int COUT = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
@@ -117,16 +127,21 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
   // read through the buffer descriptor at an out-of-range offset (hardware returns zeros).
   f32x4 pf[NPF];
   unsigned goff[NPF], yx[NPF];
+  const unsigned s3row = S3IN ? (unsigned)(p.Cin >> 5) * 12u * (unsigned)p.Wi : 0u;   // 16-B units per input row y (S3)
 #pragma unroll
   for (int k = 0; k < NPF; ++k) {
     const int e = tid + k * NTHREADS;
     const int v = e / NQ, q = e % NQ;
     const int yy = v / IX, xx = v % IX;
-    goff[k] = 4u * (unsigned)((yy * p.Wi + xx) * p.Cin + 4 * q);
+    if constexpr (S3IN)         // unit (plane q / 2, g = q & 1 of the chunk's unit pair) of voxel (yy, xx)
+      goff[k] = 16u * ((unsigned)yy * s3row + (unsigned)(4 * (q >> 1) + (q & 1)) * (unsigned)p.Wi + (unsigned)xx);
+    else
+      goff[k] = 4u * (unsigned)((yy * p.Wi + xx) * p.Cin + 4 * q);
     yx[k] = e < NE ? ((unsigned)yy << 16 | (unsigned)xx) : 0x7fff0000u;   // tail: never in range
   }
   const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.wbytes);
-  const unsigned plane_bytes = 4u * (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)p.Cin;
+  const unsigned plane_bytes = S3IN ? 16u * s3row * (unsigned)p.Hi
+                                    : 4u * (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)p.Cin;
 
   // (tile, dz, ck) of the chunk being multiplied and of the one being staged
   struct Pos { int t, dz, ck, yb, xb, z; unsigned base; };   // base: byte offset of the box origin in the tile's own z-plane (mod 2^32)
@@ -135,7 +150,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
     q.xb = (id % p.ntx) * 32 * S - DIL; id /= p.ntx;
     q.yb = (id % p.nty) * TY * S - DIL; id /= p.nty;
     q.z = (id % p.Do) * S; const int b = id / p.Do;          // input plane of the centre z-tap
-    q.base = (unsigned)(4l * (((((long)b * p.Di + q.z) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
+    if constexpr (S3IN)
+      q.base = (unsigned)(16l * ((((long)b * p.Di + q.z) * p.Hi + q.yb) * (long)s3row + q.xb));
+    else
+      q.base = (unsigned)(4l * (((((long)b * p.Di + q.z) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
     return q;
   };
   auto advance = [&](Pos q) {                   // next chunk: ck fastest, then dz, then the tile
@@ -158,7 +176,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
     }
   };
   auto chunk_rsrc = [&](const Pos& q, bool live) {
-    const long off = (long)(q.dz - KZ / 2) * (long)plane_bytes + (long)q.ck * (CK * 4);
+    const long off = (long)(q.dz - KZ / 2) * (long)plane_bytes +
+                     (S3IN ? (long)((q.ck >> 1) * 12 + 2 * (q.ck & 1)) * p.Wi * 16 : (long)q.ck * (CK * 4));
     return make_rsrc(reinterpret_cast<const char*>(p.x) + off, live ? p.xbytes : 0u);
   };
   auto live_of = [&](const Pos& q) {            // wave-uniform: a tile exists and its z-tap plane is inside
@@ -171,8 +190,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
   // LDS write address of this thread's quad k.  S = 1: voxel (tid >> 2) + 64 k, an immediate
   // per k; S = 2: the even/odd row layout, one register per k.
   const int wr_off = (tid >> 2) * PITCH + (tid & 3) * 8;
-  int wofs[S == 1 ? 1 : NPF];
-  if constexpr (S == 2) {
+  int wofs[(S == 1 && !S3IN) ? 1 : NPF];
+  if constexpr (S3IN) {
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      const int e = tid + k * NTHREADS;
+      const int v = min(e, NE - 1) / NQ, q = e % NQ, yy = v / IX, xx = v % IX;
+      const int vox = (S == 1) ? v : yy * RP + (xx & 1) * 33 + (xx >> 1);
+      wofs[k] = e < NE ? vox * PITCH + (q >> 1) * 32 + (q & 1) * 16
+                       : (IY * RP) * PITCH + (tid % 28) * 16;    // the tail: spare voxels behind the image
+    }
+  } else if constexpr (S == 2) {
 #pragma unroll
     for (int k = 0; k < NPF; ++k) {
       const int e = min(tid + k * NTHREADS, NE - 1);
@@ -195,6 +223,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
   // the gaps of one MFMA group.
   auto convert = [&](auto kc, auto hc, unsigned char* img) {
     constexpr int k = decltype(kc)::value, half = decltype(hc)::value;
+    if constexpr (S3IN) {                       // a plain copy: the element is already split
+      *reinterpret_cast<f32x4*>(img + wofs[k]) = pf[k];
+      return;
+    }
     float r0 = half ? pf[k].z : pf[k].x, r1 = half ? pf[k].w : pf[k].y;
     unsigned pl[3];
 #pragma unroll
@@ -236,7 +268,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
     static_for<0, AHEAD - 1>([&](auto ic) { wload(ic, 0u); });
     static_for<0, NPF>([&](auto kc) {
       convert(kc, std::integral_constant<int, 0>{}, lds_raw);
-      convert(kc, std::integral_constant<int, 1>{}, lds_raw);
+      if constexpr (!S3IN) convert(kc, std::integral_constant<int, 1>{}, lds_raw);
     });
   }
   int cur = 0;                                  // image holding the current chunk
@@ -308,8 +340,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
         // element j was requested in group j and is converted in groups CONV0 + 2j, + 2j + 1
 #if !(defined(DSM_ABLATE) && DSM_ABLATE == 1)
         static_for<0, CPG>([&](auto jc) {
-          constexpr int hidx = (s - CONV0) * CPG + decltype(jc)::value;   // half-element index
-          if constexpr (s >= CONV0 && hidx < 2 * NPF)
+          constexpr int hidx = (s - CONV0) * CPG + decltype(jc)::value;   // half-element (S3: element) index
+          if constexpr (S3IN) {
+            if constexpr (s >= CONV0 && hidx < NPF)
+              convert(std::integral_constant<int, hidx>{}, std::integral_constant<int, 0>{}, nimg);
+          } else if constexpr (s >= CONV0 && hidx < 2 * NPF)
             convert(std::integral_constant<int, hidx / 2>{}, std::integral_constant<int, hidx % 2>{}, nimg);
         });
 #endif
@@ -589,8 +624,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void deconv_bf16x3_kernel(ConvParams p
 
 // weights -> section 2 of the packed buffer: [Cin/16][tap][Cout/32][plane][lane][8 bf16],
 // tap = dz * 9 + t9 (ntaps = 27) or t9 (ntaps = 9)
+// s3order: input channels in the k-slot order of an S3-input kernel (see conv_bf16x3_kernel)
 __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                           int Cin, int Cout, int transposed, int ntaps, int cin_src) {
+                                           int Cin, int Cout, int transposed, int ntaps, int cin_src,
+                                           int s3order) {
   const long n = (long)Cin * Cout * ntaps;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
@@ -600,7 +637,9 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned
   const int lane = i & 63; i >>= 6;
   const int n_ = i % NT; i /= NT;
   const int tap = i % ntaps; const int c16 = i / ntaps;
-  const int cin = 16 * c16 + 8 * (lane >> 5) + j, cout = 32 * n_ + (lane & 31);
+  const int cin = s3order ? 32 * (c16 >> 1) + 16 * (j >> 2) + 4 * (2 * (c16 & 1) + (lane >> 5)) + (j & 3)
+                          : 16 * c16 + 8 * (lane >> 5) + j;
+  const int cout = 32 * n_ + (lane & 31);
   const long src = transposed ? (((long)cin * Cout + cout) * ntaps + tap)
                               : (((long)cout * cin_src + cin) * ntaps + tap);
   float v = cin < cin_src ? w[src] : 0.f;

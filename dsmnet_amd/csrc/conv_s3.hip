@@ -257,7 +257,7 @@ constexpr int S3_NV = S3_IY * S3_IX;              // 340 voxels of the halo box
 constexpr int S3_NVP = 352;                       // padded to a multiple of 16: (plane, g) rows 256-B aligned
 constexpr int S3_ROW = S3_NVP * 16;               // 5,632 B
 constexpr int S3_IMG = 12 * S3_ROW;               // 67,584 B = 66 pieces of 1 KiB
-constexpr int S3_NPIECE = S3_IMG / 1024;          // 66
+static_assert(S3_IMG % 1024 == 0, "the image is 66 whole 1-KiB pieces");
 constexpr int S3_IMGP = 68 * 1024;                // image stride: two spare pieces take waves 2, 3's 17th store
 constexpr int S3_NPW = 17;                        // pieces per wave (waves 2, 3: the 17th is the spare)
 constexpr int S3_NSTEP = 27;

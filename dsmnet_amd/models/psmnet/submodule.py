@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import costvolume as cv
-from ...blocks2d import ConvBN2d, _Folded2d, run_conv2d, stage_image_nhwc16
+from ...blocks2d import ConvBN2d, _Folded2d, run_conv2d, s3in_ok, s3out_ok, stage_image_nhwc16
 from ...blocks3d import ConvBN3d, _versions
 
 
@@ -46,6 +46,19 @@ class BasicBlock(nn.Module):
         y = self.conv1[0](x, relu=True)                    # convbn + the Sequential's ReLU
         skip = x if self.downsample is None else self.downsample(x)
         return self.conv2(y, residual=skip)                # convbn + skip add, no ReLU after
+
+    def forward_s3(self, x_f, x_s, want_s3):
+        """Eval fast path: ``x_f`` the block's input as an fp32 map (skip addition, 1x1 / stride-2
+        layers), ``x_s`` the same map as an S3Volume or None; activations between two bf16x3
+        convolutions travel pre-split (csrc/conv_s3.hip: S3).  Returns (out_f, out_s or None)."""
+        c1, c2 = self.conv1[0], self.conv2
+        x1 = x_s if (x_s is not None and s3in_ok(c1[0])) else x_f
+        mid_s3 = s3in_ok(c2[0]) and s3out_ok(c1[0])
+        y = c1(x1, relu=True, out="s3" if mid_s3 else "f32")
+        skip = x_f if self.downsample is None else self.downsample(x_f)
+        if want_s3 and s3out_ok(c2[0]):
+            return c2(y, residual=skip, out="both")
+        return c2(y, residual=skip), None
 
 
 class disparityregression(nn.Module):
@@ -131,14 +144,33 @@ class feature_extraction(nn.Module):
             self._spp_key = key
         return self._spp_cache
 
+    def _trunk_s3(self, x):
+        """firstconv .. layer4 in eval mode with S3 hand-over between the bf16x3 convolutions.
+        Returns (raw, skip) as fp32 maps."""
+        x = self.firstconv[0](stage_image_nhwc16(x), relu=True)    # 3 -> 32, stride 2: fp32-input MFMA
+        x_s = self.firstconv[2](x, relu=True, out="s3")
+        x_f, x_s = self.firstconv[4](x_s, relu=True, out="both")
+        blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
+        raw = None
+        for i, b in enumerate(blocks):
+            last = i + 1 == len(blocks)
+            x_f, x_s = b.forward_s3(x_f, x_s, want_s3=not last)
+            if b is self.layer2[-1]:
+                raw = x_f
+        return raw, x_f
+
     def forward(self, x):
-        if x.is_cuda and not self.training and not torch.is_grad_enabled():
-            x = stage_image_nhwc16(x)                      # NHWC, 3 -> 16 staged channels
-        for i in (0, 2, 4):
-            x = self.firstconv[i](x, relu=True)
-        x = self.layer1(x)
-        raw = self.layer2(x)
-        skip = self.layer4(self.layer3(raw))
+        fast = x.is_cuda and not self.training and not torch.is_grad_enabled()
+        if fast and cv.get_option("s3") and cv.get_option_bf16x3():
+            raw, skip = self._trunk_s3(x)
+        else:
+            if fast:
+                x = stage_image_nhwc16(x)                  # NHWC, 3 -> 16 staged channels
+            for i in (0, 2, 4):
+                x = self.firstconv[i](x, relu=True)
+            x = self.layer1(x)
+            raw = self.layer2(x)
+            skip = self.layer4(self.layer3(raw))
         if skip.is_cuda and not self.training and not torch.is_grad_enabled():
             x = cv.spp_head(raw, skip, *self._spp_params())       # three launches (csrc/spp.hip)
         else:

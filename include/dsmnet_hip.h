@@ -148,6 +148,11 @@ typedef struct dsm_conv3d_args {
    * dsm_conv3d_s3_fwd; `y` may then be NULL.  Only the bf16x3 3-D kernels have this epilogue
    * (Conv3d / ConvTranspose3d with Cout in {32, 64}); DSM_ERR_UNSUPPORTED otherwise. */
   void*        y_s3;
+  /* ABI v4: the input in the S3 format instead of `x` (which is then NULL): Conv3d / Conv2d
+   * (not transposed) on the bf16x3 kernels, Cin % 32 == 0, w_packed from
+   * dsm_conv_pack_weights_s3in.  The operand split then happened once, in the producer's
+   * epilogue, and the kernel's staging is a plain copy. */
+  const void*  x_s3;
 } dsm_conv3d_args;
 
 /* bytes of the packed (MFMA-fragment-ordered) weight buffer */
@@ -164,6 +169,11 @@ int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed,
 size_t dsm_conv_packed_weight_bytes(int Cin, int Cout, int kd, int k);
 int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, int Cin, int Cout,
                           int kd, int k, dsm_stream_t stream);
+
+/* weights for a launch with dsm_conv3d_args.x_s3 set (same size as dsm_conv_packed_weight_bytes):
+ * torch layout (Cout, Cin, [kd,] 3, 3), kd in {1, 3}, Cin % 32 == 0 */
+int dsm_conv_pack_weights_s3in(const void* w_torch, void* w_packed, int Cin, int Cout, int kd,
+                               int k, dsm_stream_t stream);
 
 int dsm_conv3d_fwd(const dsm_conv3d_args* args, dsm_stream_t stream);
 

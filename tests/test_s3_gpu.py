@@ -152,3 +152,59 @@ def test_psmnet_paths_agree(cv, golden_e2e):
         for pname, p in zip(("pred3", "pred2", "pred1"), outs[name]):
             golden_e2e.compare("e2e.psmnet." + pname, p, 1e-3)
     assert maxerr(outs["default"][0], outs["r01"][0]) <= 1e-3
+
+
+@pytest.mark.parametrize("cin,cout,stride,shape", [
+    (32, 64, 2, (1, 6, 12, 40)), (64, 64, 2, (1, 5, 9, 37)), (64, 64, 1, (2, 3, 7, 35)),
+    (32, 32, 1, (1, 5, 17, 33)), (64, 32, 1, (1, 4, 16, 64)),
+])
+def test_conv3d_bf16x3_reads_s3_input(cv, cin, cout, stride, shape):
+    """The bf16x3 convolution with its input handed over pre-split (x_s3): equal to the same layer
+    fed the fp32 tensor up to summation order, and to the CPU reference."""
+    B, D, H, W = shape
+    x = seeded(61, B, cin, D, H, W)
+    w = seeded(62, cout, cin, 3, 3, 3, scale=0.05)
+    sc, sh = seeded(63, cout).abs() + 0.5, seeded(64, cout)
+    want = F.conv3d(x.double(), w.double(), stride=stride, padding=1)
+    want = (want * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1)).relu().float()
+    assert cv.conv_s3in_eligible(cin, cout, stride, False)
+    xs = cv.s3_from_tensor(x.cuda())
+    y, ys3 = cv.conv3d_block(xs, cv.pack_conv_weight_s3in(w.cuda()), cout, sc.cuda(), sh.cuda(),
+                             stride=stride, relu=1, out="both")
+    ref = cv.conv3d_block(x.cuda(), cv.pack_conv3d_weight(w.cuda(), False), cout, sc.cuda(), sh.cuda(),
+                          stride=stride, relu=1)
+    tol = 2e-5 * max(1.0, want.abs().max().item())
+    assert maxerr(y, want) <= tol and maxerr(y, ref) <= tol
+    assert torch.equal(ys3.to_tensor(), y)
+
+
+@pytest.mark.parametrize("cin,cout,dil,hw,res", [
+    (32, 32, 1, (192, 96), True),      # 16-row tiles
+    (32, 32, 1, (20, 45), False),      # 8-row tiles, ragged
+    (64, 64, 1, (33, 70), True),
+    (64, 128, 1, (24, 40), False),
+    (128, 128, 1, (17, 33), True),
+    (128, 128, 2, (24, 50), True),     # dilation 2 (layer4)
+])
+def test_conv2d_bf16x3_reads_s3_input(cv, cin, cout, dil, hw, res):
+    """2-D tower layers (models/psmnet/submodule.py:10-43) with the S3 hand-over between them."""
+    H, W = hw
+    x = seeded(71, 2, cin, H, W)
+    w = seeded(72, cout, cin, 3, 3, scale=0.05)
+    sc, sh = seeded(73, cout).abs() + 0.5, seeded(74, cout)
+    r = seeded(75, 2, cout, H, W) if res else None
+    want = F.conv2d(x.double(), w.double(), padding=dil, dilation=dil)
+    want = want * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    if res:
+        want = want + r.double()
+    want = want.float()
+    assert cv.conv_s3in_eligible(cin, cout, 1, False, kd=1, k=3, dil=dil)
+    xs = cv.s3_from_tensor(x.cuda().unsqueeze(2))                      # the map as a (B,C,1,H,W) volume
+    y, ys3 = cv.conv2d_block(xs, cv.pack_conv_weight_s3in(w.cuda()), cout, sc.cuda(), sh.cuda(),
+                             None if r is None else r.cuda(), dilation=dil, out="both")
+    assert tuple(y.shape) == (2, cout, H, W)
+    assert maxerr(y, want) <= 2e-5 * max(1.0, want.abs().max().item())
+    assert torch.equal(ys3.to_tensor().squeeze(2), y)
+    ref = cv.conv2d_block(x.cuda(), cv.pack_conv2d_weight(w.cuda()), cout, sc.cuda(), sh.cuda(),
+                          None if r is None else r.cuda(), dilation=dil)
+    assert maxerr(y, ref) <= 2e-5 * max(1.0, want.abs().max().item())
