@@ -18,7 +18,7 @@ from .blocks3d import _versions
 
 def s3in_ok(conv):
     """Can ``conv``'s kernel read its input in the S3 format (costvolume.S3Volume)?"""
-    if not (cv.get_option("s3") and isinstance(conv, nn.Conv2d)):
+    if not (cv.get_option("s3") and cv.get_option("s3in") and isinstance(conv, nn.Conv2d)):
         return False
     k, s, d, p = conv.kernel_size, conv.stride, conv.dilation, conv.padding
     if k[0] != k[1] or s[0] != s[1] or d[0] != d[1] or p[0] != p[1] or conv.groups != 1:

@@ -132,7 +132,7 @@ def _s3_layer(conv):
 
 def _s3in_layer(conv):
     """Can this layer's bf16x3 kernel read an S3 input?"""
-    return (cv.get_option("s3") and isinstance(conv, nn.Conv3d) and
+    return (cv.get_option("s3") and cv.get_option("s3in") and isinstance(conv, nn.Conv3d) and
             cv.conv_s3in_eligible(conv.in_channels, conv.out_channels, conv.stride[0], False))
 
 

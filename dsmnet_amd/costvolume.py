@@ -384,6 +384,10 @@ def conv_s3in_eligible(cin, cout, stride, transposed, kd=3, k=3, dil=1):
     the variants compiled there): 3x3(x3), not transposed, Cin % 32 == 0."""
     if transposed or k != 3 or cin % 32 != 0 or not get_option_bf16x3():
         return False
+    return _conv_s3in_compiled(cout, stride, kd, dil)
+
+
+def _conv_s3in_compiled(cout, stride, kd, dil):
     if kd == 3:
         return dil == 1 and ((stride == 1 and cout in (32, 64)) or (stride == 2 and cout == 64))
     return stride == 1 and ((dil == 1 and cout in (32, 64, 128)) or (dil == 2 and cout == 128))
@@ -418,14 +422,19 @@ def conv3d_plan_name(args):
 # S3 activations (fp32 stored pre-split for the bf16 matrix pipe) and the z-sliding convolution
 # that consumes them -- csrc/conv_s3.hip, include/dsmnet_hip.h "S3"
 # ----------------------------------------------------------------------------
-_OPTIONS = {"s3": True, "fuse_volume": True}
+_OPTIONS = {"s3": True, "fuse_volume": True, "s3in": False}
 
 
 def set_option(name, value):
     """Host-side switches for A/B runs and tests (no environment variable is read by the library):
     ``s3`` -- eval-mode 32-channel stride-1 3-D layers run on the z-sliding S3 kernel;
     ``fuse_volume`` -- PSMNet's eval forward never materialises the cost volume: the first 3-D
-    convolution stages it from the split feature maps."""
+    convolution stages it from the split feature maps;
+    ``s3in`` -- the OTHER bf16x3 convolutions (2-D towers, stride-2 and 64-channel 3-D layers) also
+    take their input pre-split.  Off by default: measured in one process on the PSMNet forward
+    (scripts/ab_paths.py, r02) it LOSES 4-17 % on every one of those kernels -- their operand
+    split already rides in the shadow of the 32-cycle 32x32x16 MFMAs, while an S3 input costs 50 %
+    more staged bytes and its producer an epilogue split."""
     if name not in _OPTIONS:
         raise KeyError(name)
     old = _OPTIONS[name]

@@ -44,12 +44,12 @@ class hourglass(nn.Module):
         """Reference signature plus ``skip``: when given, ``out + skip`` (the caller's
         ``myadd_3d(out, cost0)``, stackhourglass.py:139-145) is fused into conv6;
         ``out_format`` ("f32" | "both"): the format(s) conv6 writes ``out`` in (eval only)."""
-        if out_format == "f32":                                    # training / autograd / S3 off
+        if out_format == "f32" or not isinstance(x, cv.S3Volume):  # training / autograd / fp32 hand-over
             out = self.conv1(x)                                    # 1/4 -> 1/8
             pre = self.conv2(out, residual=postsqu, relu=True)     # relu(conv2 (+ postsqu))
             out = self.conv4(self.conv3(pre))                      # 1/8 -> 1/16
             post = self.conv5(out, residual=presqu if presqu is not None else pre, relu=True)
-            return self.conv6(post, residual=skip), pre, post      # 1/8 -> 1/4
+            return self.conv6(post, residual=skip, out=out_format), pre, post      # 1/8 -> 1/4
         # eval: `x` is an S3Volume; every convolution hands its result to the next one pre-split
         # (".s"); fp32 copies (".f") only where a skip addition or a transposed convolution reads it
         out_s = self.conv1(x, out="s3")
@@ -120,10 +120,16 @@ class PSMNet(nn.Module):
         # same dataflow; tensors that feed an S3 layer travel as S3 (".s"), those that feed the
         # fp32 kernels (stride-2 convolutions, skip additions) as fp32 (".f")
         c0a_f, c0a_s = self.dres0(cost, out="both")
-        cost0, cost0_s = self.dres1(c0a_s, residual=c0a_f, out="both")
-        o1_s, pre1, post1 = self.dres2(cost0_s, None, None, skip=cost0, out_format="s3")
-        o2_s, pre2, post2 = self.dres3(o1_s, pre1, post1, skip=cost0, out_format="s3")
-        o3_s, pre3, post3 = self.dres4(o2_s, pre1, post2, skip=cost0, out_format="s3")
+        if cv.get_option("s3in"):              # the hourglasses read S3 too (off by default: slower)
+            cost0, cost0_s = self.dres1(c0a_s, residual=c0a_f, out="both")
+            o1_s, pre1, post1 = self.dres2(cost0_s, None, None, skip=cost0, out_format="s3")
+            o2_s, pre2, post2 = self.dres3(o1_s, pre1, post1, skip=cost0, out_format="s3")
+            o3_s, pre3, post3 = self.dres4(o2_s, pre1, post2, skip=cost0, out_format="s3")
+        else:
+            cost0 = self.dres1(c0a_s, residual=c0a_f)
+            (o1_f, o1_s), pre1, post1 = self.dres2(cost0, None, None, skip=cost0, out_format="both")
+            (o2_f, o2_s), pre2, post2 = self.dres3(o1_f, pre1, post1, skip=cost0, out_format="both")
+            o3_s, pre3, post3 = self.dres4(o2_f, pre1, post2, skip=cost0, out_format="s3")
         cost1 = self.classif1(o1_s)
         cost2 = self.classif2(o2_s, residual=cost1)
         cost3 = self.classif3(o3_s, residual=cost2)

@@ -161,7 +161,7 @@ class feature_extraction(nn.Module):
 
     def forward(self, x):
         fast = x.is_cuda and not self.training and not torch.is_grad_enabled()
-        if fast and cv.get_option("s3") and cv.get_option_bf16x3():
+        if fast and cv.get_option("s3") and cv.get_option("s3in") and cv.get_option_bf16x3():
             raw, skip = self._trunk_s3(x)
         else:
             if fast:

@@ -1,0 +1,53 @@
+"""Same-process A/B of the PSMNet eval forward with host-side options toggled (interleaved rounds):
+    s3 on/off, fuse_volume on/off, and optional per-stage breakdown from the LaunchTimer."""
+import sys
+import time
+
+sys.path.insert(0, ".")
+import torch
+
+from dsmnet_amd import calibrate, costvolume as cv
+from dsmnet_amd.models import model_create_by_name
+
+H, W = 384, 1280
+torch.manual_seed(0)
+dev = "cuda"
+m = model_create_by_name("psmnet", 192).to(dev)
+g = torch.Generator().manual_seed(1)
+l, r = torch.rand(1, 3, H, W, generator=g).to(dev), torch.rand(1, 3, H, W, generator=g).to(dev)
+calibrate.calibrate_batchnorm(m, l, r)
+calibrate.calibrate_psmnet_heads(m, l, r)
+m.eval()
+configs = {"s3+fuse": (True, True), "s3": (True, False), "r01": (False, False)}  # (s3, fuse_volume); s3in stays off
+if len(sys.argv) > 1:
+    configs = {k: v for k, v in configs.items() if k in sys.argv[1:]}
+res = {k: [] for k in configs}
+stages = {}
+with torch.no_grad():
+    for rnd in range(6):
+        for name, (s3, fuse) in configs.items():
+            cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse)
+            for _ in range(2):
+                m(l, r)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                m(l, r)
+            torch.cuda.synchronize()
+            if rnd:
+                res[name].append((time.perf_counter() - t0) / 10 * 1e3)
+    for name, (s3, fuse) in configs.items():
+        cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse)
+        t = cv.LaunchTimer()
+        cv.set_timer(t)
+        for _ in range(5):
+            m(l, r)
+        torch.cuda.synchronize()
+        cv.set_timer(None)
+        stages[name] = {k: (v["ms"] / 5, v["launches"] / 5) for k, v in t.summary().items()}
+for name, t in res.items():
+    t = sorted(t)
+    print("%-10s eager forward: median %.3f ms  min %.3f ms" % (name, t[len(t) // 2], t[0]))
+names = sorted({k for s in stages.values() for k in s})
+for k in names:
+    print("%-62s" % k + "  ".join("%s %6.3f ms (%2d)" % (c, stages[c].get(k, (0, 0))[0], stages[c].get(k, (0, 0))[1]) for c in stages))

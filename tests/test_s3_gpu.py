@@ -130,9 +130,9 @@ def test_bf16x3_kernels_write_the_same_result_as_s3(cv, cin, cout, stride, trans
 
 
 def test_psmnet_paths_agree(cv, golden_e2e):
-    """PSMNet eval forward three ways -- default (virtual volume + S3 trunk layers), S3 layers on
-    a materialised fp32 volume, and the r01 path (no S3 at all): each within 1e-3 px of the
-    reference golden."""
+    """PSMNet eval forward four ways -- default (virtual volume + z-sliding S3 layers), S3 layers on
+    a materialised fp32 volume, S3 hand-over everywhere (towers and hourglasses too: the ``s3in``
+    option), and the r01 path (no S3 at all): each within 1e-3 px of the reference golden."""
     from tests.golden.make_goldens import images
     from tests.helpers import golden_state
     from dsmnet_amd.models import model_create_by_name
@@ -142,13 +142,14 @@ def test_psmnet_paths_agree(cv, golden_e2e):
     m.load_state_dict(sd, strict=True)
     m = m.cuda().eval()
     outs = {}
-    for name, s3, fuse in (("default", True, True), ("s3-on-fp32-volume", True, False), ("r01", False, False)):
-        o1, o2 = cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse)
+    for name, s3, fuse, s3in in (("default", True, True, False), ("s3-on-fp32-volume", True, False, False),
+                                 ("s3-everywhere", True, True, True), ("r01", False, False, False)):
+        o1, o2, o3 = cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse), cv.set_option("s3in", s3in)
         try:
             with torch.no_grad():
                 outs[name] = m(imL.cuda(), imR.cuda())[1]
         finally:
-            cv.set_option("s3", o1), cv.set_option("fuse_volume", o2)
+            cv.set_option("s3", o1), cv.set_option("fuse_volume", o2), cv.set_option("s3in", o3)
         for pname, p in zip(("pred3", "pred2", "pred1"), outs[name]):
             golden_e2e.compare("e2e.psmnet." + pname, p, 1e-3)
     assert maxerr(outs["default"][0], outs["r01"][0]) <= 1e-3
