@@ -16,7 +16,9 @@ def _act():
 
 
 class feature2d(nn.Module):
-    """2-D tower at 1/2 resolution (stock torch layers; outside the hot path)."""
+    """2-D tower at 1/2 resolution (models/gcnet.py:14-29).  Eval mode on the GPU: the eight
+    residual blocks and the closing biased 3x3 convolution -- 17 of the 18 convolutions -- run on
+    the MFMA kernel with folded BN (blocks2d); the 5x5 stride-2 stem (3 -> 32) stays a stock layer."""
 
     def __init__(self, num_F=32):
         super(feature2d, self).__init__()
@@ -27,7 +29,13 @@ class feature2d(nn.Module):
         self.conv2 = nn.Conv2d(32, 32, kernel_size=3, stride=1, padding=1)
 
     def forward(self, x):
-        return self.conv2(self.block1(self.conv1(x)))
+        x = self.block1(self.conv1(x))
+        if x.is_cuda and not self.training and not torch.is_grad_enabled():
+            from ..blocks2d import _Folded2d, run_conv2d
+            if not hasattr(self, "_fold"):
+                self._fold = _Folded2d()
+            return run_conv2d(self._fold, self.conv2, None, x).contiguous()   # NCHW for the volume build
+        return self.conv2(x)
 
 
 # (name, Cin multiplier, Cout multiplier, stride) of the 14 convolutions, in definition order

@@ -8,6 +8,7 @@ cost-volume path runs.
 """
 import math
 
+import torch
 import torch.nn as nn
 
 from .. import costvolume as cv
@@ -112,8 +113,26 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if x.is_cuda and not self.training and not torch.is_grad_enabled():
+            # eval on the GPU: both 3x3 convolutions on the MFMA kernel (blocks2d), BN folded,
+            # ReLU and the skip addition in their epilogues -- two launches per block
+            from ..blocks2d import _Folded2d, run_conv2d
+            if not hasattr(self, "_folds"):
+                self._folds = (_Folded2d(), _Folded2d())
+            skip = x if self.downsample is None else self.downsample(x)
+            y = run_conv2d(self._folds[0], self.conv1, self.bn1, x, relu=True)
+            return run_conv2d(self._folds[1], self.conv2, self.bn2, y, residual=skip, relu=True)
         y = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
         return self.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_folds":                      # fold caches are per instance, re-made on use
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
 
 def conv_res(inplanes, planes, blocks, stride=1):

@@ -302,3 +302,27 @@ print("ok", l0, l1, l2)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
                        cwd=__import__("os").path.dirname(__import__("os").path.dirname(__file__)))
     assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_gcnet_feature2d_runs_on_the_hip_kernels(hip_lib, golden_e2e):
+    """SURVEY 8f-1, second half: GCNet's 2-D tower (models/gcnet.py:14-29) -- its eight residual
+    blocks and the closing biased convolution are 17 launches of the MFMA convolution kernel
+    (the 5x5 stride-2 stem stays stock); the tower's output equals the oracle's."""
+    from dsmnet_amd import costvolume as cv
+    sd, cfg = golden_state(golden_e2e, "gcnet")
+    imL, _ = images(cfg["image_seed"], *cfg["hw"])
+    m = load("gcnet", sd)
+    timer = cv.LaunchTimer()
+    cv.set_timer(timer)
+    try:
+        with torch.no_grad():
+            got = m.layer2d(imL.cuda())
+    finally:
+        cv.set_timer(None)
+    torch.cuda.synchronize()
+    launches = sum(v["launches"] for k, v in timer.summary().items() if k.startswith("conv2d"))
+    assert launches == 17, timer.summary().keys()
+    with torch.no_grad():
+        want = OM.gcnet_features(OM.Net(sd), imL)
+    assert got.shape == want.shape and got.is_contiguous()
+    assert maxerr(got, want) <= 2e-5 * max(1.0, want.abs().max().item())
