@@ -17,6 +17,16 @@ DSM_F32 = 0
 DSM_NCDHW, DSM_NDHWC = 0, 1
 
 
+class Bn3dArgs(ctypes.Structure):
+    """struct dsm_bn3d_args (include/dsmnet_hip.h)."""
+    _fields_ = [("y", c_void_p), ("residual", c_void_p), ("out", c_void_p), ("gamma", c_void_p),
+                ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p),
+                ("affine", c_void_p), ("workspace", c_void_p), ("gout", c_void_p), ("dy", c_void_p),
+                ("dresidual", c_void_p), ("B", c_int), ("C", c_int),
+                ("Dy", c_int), ("Hy", c_int), ("Wy", c_int), ("Dr", c_int), ("Hr", c_int), ("Wr", c_int),
+                ("relu", c_int), ("momentum", ctypes.c_float), ("eps", ctypes.c_float)]
+
+
 class Conv3dS3Args(ctypes.Structure):
     """struct dsm_conv3d_s3_args (include/dsmnet_hip.h)."""
     _fields_ = [("x_s3", c_void_p), ("w_packed", c_void_p), ("scale", c_void_p),
@@ -69,6 +79,8 @@ SIGNATURES = {
     "dsm_conv3d_s3_packed_weight_bytes": (c_size_t, [c_int] * 2),
     "dsm_conv3d_s3_pack_weights": (c_int, [c_void_p] * 2 + [c_int] * 2 + [c_void_p]),
     "dsm_conv3d_s3_fwd": (c_int, [ctypes.POINTER(Conv3dS3Args), c_void_p]),
+    "dsm_bn3d_train_fwd": (c_int, [ctypes.POINTER(Bn3dArgs), c_void_p]),
+    "dsm_bn3d_train_bwd": (c_int, [ctypes.POINTER(Bn3dArgs), c_void_p]),
     "dsm_volume_relayout": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
     "dsm_conv_packed_weight_bytes": (ctypes.c_size_t, [c_int] * 4),
     "dsm_spp_branch_floats": (ctypes.c_size_t, [c_int] * 3),

@@ -14,6 +14,10 @@ import torch.nn as nn
 from . import costvolume as cv
 
 RELU_NONE, RELU_AFTER_ADD, RELU_BEFORE_ADD = 0, 1, 2
+_FUSED_TRAIN_BN = __import__("os").environ.get("DSM_TRAIN_BN", "fused") != "stock"
+# test hook: called with (block output, relu mode) of every fused train-mode block that ends in a
+# ReLU (the sign pattern of the ReLU's input is `out > 0` for mode 1)
+_TRAIN_RELU_HOOK = [None]
 
 
 _EPOCH = [0]
@@ -106,13 +110,27 @@ def _crop_add(y, residual):
 
 def _run_block_batch_stats(folded, conv, bn, x, residual, relu):
     """Train-mode block: convolution (forward, bwd-data and bwd-weight on the HIP kernels via
-    ``costvolume.Conv3dFunction``), then BatchNorm with batch statistics, skip add and ReLU as
-    stock torch ops (their autograd included) -- unfused, as training needs the pre-BN tensor."""
+    ``costvolume.Conv3dFunction``), then batch-statistics BatchNorm + cropped skip add + ReLU as
+    ONE autograd node of two launches each way (``costvolume.bn_add_relu3d``, csrc/bn3d.hip).
+    ``DSM_TRAIN_BN=stock`` (read by this host module) keeps the stock torch ops for A/B runs."""
     del folded
     y = cv.conv3d(x, conv.weight, conv.bias, conv.stride[0], isinstance(conv, nn.ConvTranspose3d))
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    if _FUSED_TRAIN_BN and y.shape[1] % 4 == 0 and y.shape[1] <= 256:
+        out = cv.bn_add_relu3d(y, bn.weight, bn.bias, residual,
+                               bn.running_mean if bn.track_running_stats else None,
+                               bn.running_var if bn.track_running_stats else None,
+                               relu, momentum, bn.eps)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        # the kernel updated the running statistics through raw pointers (no version bump):
+        # every eval-mode fold made from them is stale now
+        invalidate_folded_caches()
+        if _TRAIN_RELU_HOOK[0] is not None and relu != RELU_NONE:
+            _TRAIN_RELU_HOOK[0](out, relu)
+        return out
     y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                                       True, bn.momentum if bn.momentum is not None else 0.1,
-                                       bn.eps)
+                                       True, momentum, bn.eps)
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     if relu == RELU_BEFORE_ADD:

@@ -829,3 +829,79 @@ class Conv3dFunction(torch.autograd.Function):
 
 def conv3d(x, weight, bias=None, stride=1, transposed=False):
     return Conv3dFunction.apply(x, weight, bias, int(stride), bool(transposed))
+
+
+# ----------------------------------------------------------------------------
+# train-mode BatchNorm3d + cropped skip add + ReLU, fused (csrc/bn3d.hip)
+# ----------------------------------------------------------------------------
+class BnAddRelu3dFunction(torch.autograd.Function):
+    """out = relu?( batch_norm(y; batch statistics) (+ residual, cropped to the common corner) )
+    for NDHWC fp32 volumes, with explicit backward -- two launches each way instead of the
+    reference's nn.BatchNorm3d + myadd_3d + F.relu chain (and their autograd nodes).
+    ``relu``: 0 none, 1 after the addition (PSMNet), 2 before it (GCNet).  Running statistics are
+    updated in place as nn.BatchNorm3d does."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, residual, running_mean, running_var, relu, momentum, eps):
+        _require_device("bn_add_relu3d", y, gamma, beta, residual, running_mean, running_var)
+        y = to_channels_last_3d(y)
+        B, C, Dy, Hy, Wy = y.shape
+        a = _lib.Bn3dArgs()
+        a.B, a.C, a.Dy, a.Hy, a.Wy = B, C, Dy, Hy, Wy
+        oshape = (B, C, Dy, Hy, Wy)
+        if residual is not None:
+            if residual.shape[0] != B or residual.shape[1] != C:
+                raise ValueError("bn_add_relu3d: residual has shape %s" % (tuple(residual.shape),))
+            residual = to_channels_last_3d(residual)
+            a.Dr, a.Hr, a.Wr = residual.shape[2:]
+            oshape = (B, C, min(Dy, a.Dr), min(Hy, a.Hr), min(Wy, a.Wr))
+            a.residual = residual.data_ptr()
+        out = torch.empty(oshape, device=y.device, dtype=torch.float32, memory_format=_CL3D)
+        affine = torch.empty(4 * C, device=y.device, dtype=torch.float32)
+        ws = torch.empty(2 * C, device=y.device, dtype=torch.float64)
+        a.y, a.out, a.affine, a.workspace = y.data_ptr(), out.data_ptr(), affine.data_ptr(), ws.data_ptr()
+        a.gamma = None if gamma is None else gamma.data_ptr()
+        a.beta = None if beta is None else beta.data_ptr()
+        a.running_mean = None if running_mean is None else running_mean.data_ptr()
+        a.running_var = None if running_var is None else running_var.data_ptr()
+        a.relu, a.momentum, a.eps = int(relu), float(momentum), float(eps)
+        with torch.cuda.device(y.device), _timed("bn3d_train_fwd_kernels", 4.0 * (2 * y.numel() + out.numel())):
+            rc = _lib.load().dsm_bn3d_train_fwd(ctypes.byref(a), _stream())
+        _lib.check(rc, "dsm_bn3d_train_fwd")
+        ctx.save_for_backward(y, out if relu == 1 else None, affine)
+        ctx.cfg = (int(relu), None if residual is None else tuple(residual.shape), gamma is not None,
+                   beta is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        y, out, affine = ctx.saved_tensors
+        relu, rshape, has_gamma, has_beta = ctx.cfg
+        gout = gout.contiguous(memory_format=_CL3D)
+        B, C, Dy, Hy, Wy = y.shape
+        a = _lib.Bn3dArgs()
+        a.B, a.C, a.Dy, a.Hy, a.Wy = B, C, Dy, Hy, Wy
+        dy = torch.empty_like(y, memory_format=_CL3D)
+        dres = None
+        if rshape is not None:
+            a.Dr, a.Hr, a.Wr = rshape[2:]
+            if ctx.needs_input_grad[3]:
+                dres = torch.empty(rshape, device=y.device, dtype=torch.float32, memory_format=_CL3D)
+                a.dresidual = dres.data_ptr()
+            else:
+                a.residual = y.data_ptr()          # only marks "a residual shaped the output corner"
+        ws = torch.empty(2 * C, device=y.device, dtype=torch.float64)
+        a.y, a.affine, a.workspace = y.data_ptr(), affine.data_ptr(), ws.data_ptr()
+        a.out = None if out is None else out.data_ptr()
+        a.gout, a.dy, a.relu = gout.data_ptr(), dy.data_ptr(), relu
+        with torch.cuda.device(y.device), _timed("bn3d_train_bwd_kernels", 4.0 * (3 * y.numel() + gout.numel())):
+            rc = _lib.load().dsm_bn3d_train_bwd(ctypes.byref(a), _stream())
+        _lib.check(rc, "dsm_bn3d_train_bwd")
+        dbeta = ws[:C].float() if has_beta else None
+        dgamma = ws[C:].float() if has_gamma else None
+        return dy, dgamma, dbeta, dres, None, None, None, None, None
+
+
+def bn_add_relu3d(y, gamma, beta, residual, running_mean, running_var, relu, momentum, eps):
+    return BnAddRelu3dFunction.apply(y, gamma, beta, residual, running_mean, running_var, int(relu),
+                                     float(momentum), float(eps))

@@ -277,6 +277,41 @@ int dsm_conv3d_s3_pack_weights(const void* w_torch, void* w_packed, int Cin, int
                                dsm_stream_t stream);
 int dsm_conv3d_s3_fwd(const dsm_conv3d_s3_args* args, dsm_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Train-mode BatchNorm3d + cropped skip addition + ReLU on NDHWC fp32 volumes, forward and
+ * backward (dsmnet_amd/csrc/bn3d.hip) -- what convbn_3d / conv3d_bn leave to nn.BatchNorm3d,
+ * myadd_3d and F.relu in a training step of the reference (models/psmnet/submodule.py:16-19,
+ * stackhourglass.py:10-20,43-62, models/util_conv.py:150-179, util_fun.py:41-50).
+ *   fwd: batch statistics of y over (B,D,H,W) -> affine[4][C] = {gamma/std, beta - mean gamma/std,
+ *        mean, 1/std}; running statistics updated as nn.BatchNorm3d does (momentum, unbiased var);
+ *        out = relu?( y*scale + shift (+ residual) ) on the common corner of y and residual
+ *        (relu: 0 none, 1 after the addition, 2 before it).
+ *   bwd: dy (B,Dy,Hy,Wy,C), dresidual (B,Dr,Hr,Wr,C) or NULL, both fully written; afterwards
+ *        workspace[0..C) = dbeta, workspace[C..2C) = dgamma (doubles).
+ * workspace: 2*C doubles.  C % 4 == 0, C <= 256.
+ * ------------------------------------------------------------------------- */
+typedef struct dsm_bn3d_args {
+  const void*  y;             /* conv output (B,Dy,Hy,Wy,C)                          */
+  const void*  residual;      /* (B,Dr,Hr,Wr,C) or NULL                              */
+  void*        out;           /* (B,Do,Ho,Wo,C), (Do,Ho,Wo) = min(y, residual)       */
+  const float* gamma;         /* [C] or NULL (= 1)                                   */
+  const float* beta;          /* [C] or NULL (= 0)                                   */
+  float*       running_mean;  /* [C] or NULL: updated in fwd                         */
+  float*       running_var;   /* [C] or NULL                                         */
+  void*        affine;        /* float [4][C]: written by fwd, read by bwd           */
+  void*        workspace;     /* double [2][C]                                       */
+  const void*  gout;          /* bwd: d loss / d out                                 */
+  void*        dy;            /* bwd                                                 */
+  void*        dresidual;     /* bwd, or NULL                                        */
+  int B, C;
+  int Dy, Hy, Wy;
+  int Dr, Hr, Wr;
+  int relu;
+  float momentum, eps;
+} dsm_bn3d_args;
+int dsm_bn3d_train_fwd(const dsm_bn3d_args* args, dsm_stream_t stream);
+int dsm_bn3d_train_bwd(const dsm_bn3d_args* args, dsm_stream_t stream);
+
 /* NCDHW <-> NDHWC repack of an fp32 volume (used at the boundary with stock
  * torch modules that want contiguous NCDHW). to_ndhwc = 1: src NCDHW. */
 int dsm_volume_relayout(const void* src, void* dst, int B, int C, int D, int H, int W,

@@ -101,13 +101,16 @@ def _trunk_step_errors(seed, hw=(16, 40), d4=8):
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
     gfl, gfr = fl.cuda().requires_grad_(True), fr.cuda().requires_grad_(True)
+    # the product's train-mode blocks are fused (BatchNorm + add + ReLU in one kernel): the sign
+    # pattern of the ReLU's input is read off the block's output (out > 0 <=> input > 0)
+    blocks3d._TRAIN_RELU_HOOK[0] = lambda out, mode: glog.masks.append((out.detach() > 0).cpu())
     orig_t = torch.relu
-    torch.relu = glog.wrap(orig_t)                 # blocks3d's train-mode blocks call torch.relu
+    torch.relu = glog.wrap(orig_t)                 # (DSM_TRAIN_BN=stock: blocks3d calls torch.relu)
     try:
         gc = m.regularise(cv.concat_volume(gfl, gfr, d4, True))
     finally:
         torch.relu = orig_t
-    assert blocks3d.torch.relu is orig_t
+        blocks3d._TRAIN_RELU_HOOK[0] = None
     loss = sum(cv.soft_argmin(c, size).mean() for c in gc)
     assert abs(loss.item() - oloss.item()) <= 1e-3 * max(1.0, abs(oloss.item()))
     for a, b in zip(gc, costs):                                   # train-mode forward: tight
