@@ -105,9 +105,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
   // element split per group over the last 2 NPF.  S = 2 (ten elements for nine groups): every load
   // in group 0, four halves per group from group 4.  S3 input: LPG loads per group from group 0,
   // the same number of 16-byte stores per group over the last groups.
-  constexpr int LPG = S3IN ? (NPF + NGROUP / 2 - 1) / (NGROUP / 2) : ((S == 1) ? 1 : NPF);   // loads per group
+  constexpr bool SHORT = !S3IN && (S == 2 || NGROUP - 2 * NPF < 2);   // few groups per chunk (4-row tiles, stride 2)
+  constexpr int LPG = S3IN ? (NPF + NGROUP / 2 - 1) / (NGROUP / 2) : (SHORT ? NPF : 1);   // loads per group
   constexpr int CONV0 = S3IN ? NGROUP - (NPF + LPG - 1) / LPG
-                             : ((S == 1) ? NGROUP - 2 * NPF : 4);   // first group that converts / stores
+                             : (SHORT ? 4 : NGROUP - 2 * NPF);   // first group that converts / stores
   constexpr int CPG = S3IN ? LPG : (2 * NPF + (NGROUP - CONV0) - 1) / (NGROUP - CONV0);   // halves (stores) per group
   static_assert(NPF <= NGROUP * LPG && CONV0 >= 2, "staging schedule");
   static_assert(!S3IN || CONV0 > (NPF + LPG - 1) / LPG, "a store must come after its load");
