@@ -328,7 +328,7 @@ def main():
         # the launch stream): per-kernel durations for the rooflines.  Kept out of the timed
         # region because the event records themselves cost ~5 % of a step.
         timer = instrumented = None
-        volume_b2b_us = None
+        volume_b2b_us = volume_seq_us = None
         if not args.no_kernel_timing:
             timer = costvolume.LaunchTimer()
             costvolume.set_timer(timer)
@@ -339,14 +339,22 @@ def main():
             barrier()
             instrumented = time.perf_counter() - t1
             costvolume.set_timer(None)
-            # the cost-volume build launched back to back (each launch must first drain the
-            # previous one's dirty Infinity-Cache lines): the sustained-write rate, reported
-            # beside the in-forward one
-            fl, fr = model.features(left, right)
-            vols = [costvolume.concat_volume(fl, fr, MAXDISP // 4, True) for _ in range(2)]
-            del vols
-            torch.cuda.synchronize()
+            # The cost-volume build (the north-star's >= 60 %-of-HBM kernel).  The default forward
+            # never materialises the volume (dres0's first convolution stages it from the split
+            # feature maps), so the build is measured here as what it is for every other caller
+            # (training, GCNet, concat_volume as an op): (1) in sequence -- each launch right after a
+            # feature-tower pass, as in a forward that materialises it -- and (2) back to back, where
+            # every launch must first drain the previous one's dirty Infinity-Cache lines.
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            seq = []
+            for _ in range(8):
+                fl, fr = model.features(left, right)
+                e0.record()
+                vol = costvolume.concat_volume(fl, fr, MAXDISP // 4, True)
+                e1.record()
+                torch.cuda.synchronize()
+                seq.append(e0.elapsed_time(e1) * 1e3)
+                del vol
             nrep = 20
             e0.record()
             for _ in range(nrep):
@@ -354,6 +362,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             volume_b2b_us = e0.elapsed_time(e1) / nrep * 1e3
+            volume_seq_us = statistics.median(seq[1:])
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -377,8 +386,10 @@ def main():
                        "launch": launch,
                        "launcher": ("self-launched child ranks" if os.environ.get("DSM_BENCH_SELF_LAUNCHED")
                                     else ("external launcher" if world > 1 else "single process")),
-                       "conv_precision": os.environ.get("DSM_CONV_PRECISION", "bf16x3") +
-                                         " (DSM_CONV_PRECISION=fp32 keeps the fp32-input MFMA)"},
+                       "conv_precision": ("fp32-input MFMA" if costvolume.get_option("conv_fp32") else "bf16x3") +
+                                         " (DSM_CONV_PRECISION=fp32, read by the host module, keeps the fp32-input MFMA)",
+                       "trunk_path": "z-sliding S3 kernel for the 32-channel stride-1 layers, cost volume "
+                                     "never materialised" if costvolume.get_option("s3") else "r01 kernels"},
             # rank 0's per-step GPU time from one HIP event per step inside the timed region
             "step_ms": {"median": round(statistics.median(step_ms), 3), "min": round(min(step_ms), 3),
                         "max": round(max(step_ms), 3), "mean_wall": round(ms_per_step, 3)},
@@ -387,11 +398,19 @@ def main():
             roofs = kernel_rooflines(timer.summary(), args.steps)
             dominant = max(roofs, key=lambda k: roofs[k]["ms_per_step"])
             result["roofline"] = dict(roofs[dominant], kernel=dominant)
-            vol = roofs.get("volume_ndhwc_fwd_kernel") or roofs.get("volume_s3_fwd_kernel")
-            if vol is not None and volume_b2b_us:
-                vol["back_to_back_us"] = round(volume_b2b_us, 2)
-                vol["back_to_back_frac"] = round(vol["work_per_launch"] / (volume_b2b_us * 1e-6) / 1e9
-                                                 / PEAK_HBM_GBS, 4)
+            if volume_b2b_us:
+                vbytes = 4.0 * (2 * 32 * (H // 4) * (W // 4) + 64 * (MAXDISP // 4) * (H // 4) * (W // 4))
+                result["cost_volume_build"] = {
+                    "kernel": "volume_ndhwc_fwd_kernel", "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
+                    "algorithmic_bytes": vbytes,
+                    "in_sequence_us": round(volume_seq_us, 2),
+                    "in_sequence": round(vbytes / (volume_seq_us * 1e-6) / 1e9, 1),
+                    "in_sequence_frac": round(vbytes / (volume_seq_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+                    "back_to_back_us": round(volume_b2b_us, 2),
+                    "back_to_back_frac": round(vbytes / (volume_b2b_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+                    "in_forward": "not launched: the default forward stages the volume from the split "
+                                  "feature maps inside dres0's first convolution (costvolume option "
+                                  "fuse_volume); measured standalone, after a tower pass / back to back"}
             result["rooflines"] = roofs
             hip_ms = sum(v["ms_per_step"] for v in roofs.values())
             result["hip_path_ms_per_step"] = round(hip_ms, 3)
@@ -409,10 +428,9 @@ def main():
             base, err = cpu_baseline(model, left, right, preds)
             result["cpu_baseline"] = base
             result["parity_max_abs_px_vs_cpu"] = err
-        mode = os.environ.get("DSM_CONV_PRECISION", "bf16x3")
         result["precision"] = {
             "storage_and_accumulate": "f32",
-            "conv_products": ("fp32-input MFMA" if mode.startswith("f") else
+            "conv_products": ("fp32-input MFMA" if costvolume.get_option("conv_fp32") else
                               "each fp32 operand split exactly into 3 bf16 terms; 6 bf16 MFMAs per product, "
                               "dropped terms <= 3*2^-25 relative; fp32 accumulate"),
             "conv_error_vs_float64": "max rel 0.8-1.3e-6, rms 4.1-5.9e-7 on 6 layer shapes; the fp32-input MFMA "

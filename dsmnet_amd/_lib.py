@@ -15,6 +15,7 @@ c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 DSM_OK = 0
 DSM_F32 = 0
 DSM_NCDHW, DSM_NDHWC = 0, 1
+DSM_CONV_FP32_MFMA, DSM_CONV_COUT1_CHUNKED, DSM_CONV_TM_SHIFT, DSM_CONV_BLOCKS_SHIFT = 1, 2, 4, 16
 
 
 class Bn3dArgs(ctypes.Structure):
@@ -48,7 +49,7 @@ class Conv3dArgs(ctypes.Structure):
                 ("Dr", c_int), ("Hr", c_int), ("Wr", c_int),
                 ("stride", c_int), ("transposed", c_int), ("relu", c_int),
                 ("kd", c_int), ("k", c_int), ("dil", c_int), ("y_s3", c_void_p),
-                ("x_s3", c_void_p)]
+                ("x_s3", c_void_p), ("flags", c_int)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in dsmnet_hip.h

@@ -144,7 +144,7 @@ def _run_block_batch_stats(folded, conv, bn, x, residual, relu):
 
 def _s3_layer(conv):
     """Does this layer run on the z-sliding S3 kernel (given an S3 input)?"""
-    return (cv.get_option("s3") and isinstance(conv, nn.Conv3d) and
+    return (cv.get_option("s3") and cv.get_option_bf16x3() and isinstance(conv, nn.Conv3d) and
             cv.conv3d_s3_eligible(conv.in_channels, conv.out_channels, conv.stride[0], False))
 
 

@@ -350,6 +350,7 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     a.Di, a.Hi, a.Wi = Di, Hi, Wi
     a.Do, a.Ho, a.Wo = Do, Ho, Wo
     a.stride, a.transposed, a.relu = int(stride), int(transposed), int(relu)
+    a.flags = _conv_flags()
     # FLOPs as SURVEY.md section 8d counts them: 2*27*Cin*Cout per output voxel (conv) or
     # per input voxel (transposed conv)
     # (Cout = 1 runs on the VALU and is HBM-bound: input read once + output written)
@@ -375,8 +376,7 @@ def conv3d_supports_s3_out(cin, cout, stride, transposed):
 
 
 def get_option_bf16x3():
-    import os
-    return not os.environ.get("DSM_CONV_PRECISION", "").startswith("f")
+    return not _OPTIONS["conv_fp32"]
 
 
 def conv_s3in_eligible(cin, cout, stride, transposed, kd=3, k=3, dil=1):
@@ -422,7 +422,13 @@ def conv3d_plan_name(args):
 # S3 activations (fp32 stored pre-split for the bf16 matrix pipe) and the z-sliding convolution
 # that consumes them -- csrc/conv_s3.hip, include/dsmnet_hip.h "S3"
 # ----------------------------------------------------------------------------
-_OPTIONS = {"s3": True, "fuse_volume": True, "s3in": False}
+import os as _os
+
+# host-side options (the library itself reads no environment variable): "conv_precision" starts from
+# DSM_CONV_PRECISION=fp32|bf16x3 so that scripts and the parity tests can switch whole runs
+_OPTIONS = {"s3": True, "fuse_volume": True, "s3in": False,
+            "conv_fp32": _os.environ.get("DSM_CONV_PRECISION", "").startswith("f"),
+            "conv_flags": 0}
 
 
 def set_option(name, value):
@@ -438,8 +444,14 @@ def set_option(name, value):
     if name not in _OPTIONS:
         raise KeyError(name)
     old = _OPTIONS[name]
-    _OPTIONS[name] = bool(value)
+    _OPTIONS[name] = int(value) if name == "conv_flags" else bool(value)
     return old
+
+
+def _conv_flags():
+    """dsm_conv3d_args.flags of every convolution launch: ``conv_fp32`` keeps the exact fp32-input
+    MFMA kernels; ``conv_flags`` carries raw A/B bits (tile height, grid size: include/dsmnet_hip.h)."""
+    return (_lib.DSM_CONV_FP32_MFMA if _OPTIONS["conv_fp32"] else 0) | _OPTIONS["conv_flags"]
 
 
 def get_option(name):
@@ -657,6 +669,7 @@ def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     a.Do, a.Ho, a.Wo = 1, Ho, Wo
     a.stride, a.transposed, a.relu = int(stride), 0, int(relu)
     a.kd, a.k, a.dil = 1, int(k), int(dilation)
+    a.flags = _conv_flags()
     work = 2.0 * k * k * cin * cout * B * Ho * Wo
     with torch.cuda.device(dev), _timed(lambda: conv3d_plan_name(a), work):
         rc = _lib.load().dsm_conv3d_fwd(ctypes.byref(a), _stream())

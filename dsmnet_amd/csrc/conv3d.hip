@@ -102,6 +102,7 @@ struct ConvParams {
   const float* x; const float* w; const float* scale; const float* shift;
   const float* res; float* y;
   unsigned char* ys3;         // optional second output in the S3 format (conv_s3.hip); bf16x3 kernels only
+  int force_blocks;           // 0, or the persistent grid size asked for in dsm_conv3d_args.flags
   int B, Cin, Cout;
   int Di, Hi, Wi, Do, Ho, Wo, Dr, Hr, Wr;
   int relu;
@@ -1031,9 +1032,7 @@ int launch_tiles(K kernel, const ConvParams& p, size_t lds, hipStream_t s, int m
       if (nconf < 48) configured[nconf++] = (const void*)kernel;
     }
   }
-  static int force_blocks = -1;                    // DSM_CONV_BLOCKS=N: persistent-grid A/B runs
-  if (force_blocks < 0) { const char* e = getenv("DSM_CONV_BLOCKS"); force_blocks = e ? atoi(e) : 0; }
-  if (force_blocks) max_blocks = force_blocks;
+  if (p.force_blocks) max_blocks = p.force_blocks;     // dsm_conv3d_args.flags: persistent-grid A/B runs
   int blocks = p.ntiles < max_blocks ? p.ntiles : max_blocks;
   if (blocks >= 8) blocks &= ~7;                 // whole rounds over the 8 XCDs
   hipLaunchKernelGGL(kernel, dim3(blocks, ny), dim3(NTHREADS), lds, s, p);
@@ -1089,12 +1088,11 @@ size_t bf16x3_section_bytes(int Cin, int Cout, int kd, int k) {
   return (size_t)Cin * Cout * kd * 9 * 6;
 }
 
-// DSM_CONV_PRECISION=fp32 keeps every convolution on the fp32-input MFMA (A/B and parity runs).
-bool bf16x3_enabled() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("DSM_CONV_PRECISION"); on = !(e && e[0] == 'f'); }
-  return on != 0;
-}
+// dsm_conv3d_args.flags & DSM_CONV_FP32_MFMA keeps a convolution on the fp32-input MFMA (A/B and
+// parity runs).  The library reads no environment variable and keeps no switch of its own: every
+// tuning choice is an argument of the call (the plan is a pure function of the arguments).
+inline bool bf16x3_enabled(const dsm_conv3d_args* a) { return !(a->flags & DSM_CONV_FP32_MFMA); }
+inline int forced_tm(const dsm_conv3d_args* a) { return (a->flags >> DSM_CONV_TM_SHIFT) & 0xf; }
 
 template <int NT, int CK>
 int run_deconv(ConvParams p, hipStream_t s) {
@@ -1205,8 +1203,7 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
       *pl = Plan{3, 2, 0, 0, 0, 3, 3, 1};
     } else {
       DSM_REQUIRE(a->stride == 1, DSM_ERR_UNSUPPORTED);
-      static int zslide = -1;                        // DSM_COUT1_ZSLIDE=0: chunked kernel (A/B runs)
-      if (zslide < 0) { const char* e = getenv("DSM_COUT1_ZSLIDE"); zslide = e ? atoi(e) : 1; }
+      const bool zslide = !(a->flags & DSM_CONV_COUT1_CHUNKED);      // A/B runs: the chunked kernel
       *pl = Plan{(a->Cin == 32 && zslide) ? 4 : 2, 1, 0, 0, 8, 3, 3, 1};
     }
     return DSM_OK;
@@ -1215,7 +1212,7 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   const int NT = a->Cout / 32;
   // Tile height: 8 rows (TM = 2) when that still gives every CU two workgroups of work,
   // else 4 rows.  Stride 2 stages 8 channels per chunk so that two workgroups fit a CU.
-  if (a->transposed && NT <= 2 && a->Cin % 32 == 0 && bf16x3_enabled() &&
+  if (a->transposed && NT <= 2 && a->Cin % 32 == 0 && bf16x3_enabled(a) &&
       4l * a->B * a->Di * a->Hi * a->Wi * a->Cin < 0x80000000l) {
     *pl = Plan{6, 2, NT, 1, 32, 3, 3, 1};
     return DSM_OK;
@@ -1226,14 +1223,13 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
     return DSM_OK;
   }
   const bool big = (long)a->B * a->Do * dsm_cdiv(a->Ho, 8) * dsm_cdiv(a->Wo, 32) >= 1024;
-  if (a->stride == 1 && k == 3 && bf16x3_enabled() && bf16x3_section_bytes(a->Cin, a->Cout, kd, k) &&
+  if (a->stride == 1 && k == 3 && bf16x3_enabled(a) && bf16x3_section_bytes(a->Cin, a->Cout, kd, k) &&
       4l * a->B * a->Di * a->Hi * a->Wi * a->Cin < 0x80000000l) {       // OOBV must lie past the tensor
     // fp32 on the bf16 pipe.  16-row tiles (TM = 4) when they still give every CU a workgroup,
     // else 8-row tiles; 64 and 128 output channels always take 8-row tiles (accumulators).
     // (12-row tiles, which divide 96 rows into exactly 15 rounds instead of 11.25, measured 3 %
     // slower than 16-row tiles with their tail; 8-row tiles 12 % slower.)
-    static int force_tm = -1;                      // DSM_BF16X3_TM=2|4: tile-height A/B runs
-    if (force_tm < 0) { const char* e = getenv("DSM_BF16X3_TM"); force_tm = e ? atoi(e) : 0; }
+    const int force_tm = forced_tm(a);             // tile-height A/B runs
     const long tiles16 = (long)a->B * a->Do * dsm_cdiv(a->Ho, 16) * dsm_cdiv(a->Wo, 32);
     int TM = (NT == 1 && dil == 1 && tiles16 >= 224) ? 4 : 2;       // 3-D, and the 32-channel 2-D maps at 1/2 resolution
     // 64 output channels on a small volume (the bottom of PSMNet's hourglass, 12 x 24 x 80:
@@ -1246,7 +1242,7 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
     *pl = Plan{5, 1, NT, TM, 16, kd, 3, dil};
     return DSM_OK;
   }
-  if (a->stride == 2 && kd == 3 && NT == 2 && bf16x3_enabled() &&
+  if (a->stride == 2 && kd == 3 && NT == 2 && bf16x3_enabled(a) &&
       4l * a->B * a->Di * a->Hi * a->Wi * a->Cin < 0x80000000l) {
     *pl = Plan{5, 2, 2, 1, 16, 3, 3, 1};           // stride 2 on the bf16 pipe: 4-row tiles, Cout = 64
     return DSM_OK;
@@ -1257,8 +1253,7 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
     return DSM_OK;
   }
   if (a->stride == 1) {
-    static int force_tm = -1;                      // DSM_CONV3D_TM=1|2: tile-height A/B runs
-    if (force_tm < 0) { const char* e = getenv("DSM_CONV3D_TM"); force_tm = e ? atoi(e) : 0; }
+    const int force_tm = forced_tm(a) <= 2 ? forced_tm(a) : 0;     // tile-height A/B runs
     const int TM = force_tm ? force_tm : ((big && NT <= 2) ? 2 : 1);
     *pl = Plan{0, 1, NT, TM, (NT == 2 && TM == 2) ? 8 : 16, 3, 3, 1};   // <1,2,2,16> would spill
   } else {
@@ -1309,6 +1304,7 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   p.x = a->x_s3 ? (const float*)a->x_s3 : (const float*)a->x; p.w = (const float*)a->w_packed; p.scale = a->scale;
   p.shift = a->shift; p.res = (const float*)a->residual; p.y = (float*)a->y;
   p.ys3 = (unsigned char*)a->y_s3;
+  p.force_blocks = (a->flags >> DSM_CONV_BLOCKS_SHIFT) & 0xffff;
   p.B = a->B; p.Cin = a->Cin; p.Cout = a->Cout;
   p.Di = a->Di; p.Hi = a->Hi; p.Wi = a->Wi; p.Do = a->Do; p.Ho = a->Ho; p.Wo = a->Wo;
   p.Dr = a->Dr; p.Hr = a->Hr; p.Wr = a->Wr; p.relu = a->relu;

@@ -290,16 +290,12 @@ static int check_sa(const void* cost, const void* disp, int B, int Dc, int Hc, i
   return DSM_OK;
 }
 
-// DSPLIT can be forced for A/B measurements (profiles/): DSM_SOFTARGMIN_DSPLIT=1|2|4
+// Disparity segments per pixel handled by separate lanes (merged with __shfl_xor): 4, fewer only
+// for very short disparity ranges.  (A/B history, r01: 4 beat 2 and 1 at D = 192)
 static int pick_dsplit(int D) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("DSM_SOFTARGMIN_DSPLIT");
-    forced = e ? atoi(e) : 0;
-  }
-  int ds = forced > 0 ? forced : 4;
+  int ds = 4;
   while (ds > 1 && D < 2 * ds) ds >>= 1;
-  return (ds == 1 || ds == 2 || ds == 4) ? ds : 4;
+  return ds;
 }
 
 extern "C" int dsm_soft_argmin_fwd(const void* cost, void* disp, void* stats, int B, int Dc,
@@ -320,9 +316,7 @@ extern "C" int dsm_soft_argmin_fwd(const void* cost, void* disp, void* stats, in
   hipStream_t s = (hipStream_t)stream;
   dsm_clear_stale_error();
 #define SA_LAUNCH(UP, DS) hipLaunchKernelGGL((soft_argmin_fwd_kernel<UP, DS>), grid, block, 0, s, p)
-  static int generic_only = -1;                       // DSM_SOFTARGMIN_GENERIC=1 forces the generic kernel (A/B)
-  if (generic_only < 0) { const char* e = getenv("DSM_SOFTARGMIN_GENERIC"); generic_only = e ? atoi(e) : 0; }
-  if (up && !generic_only && D == 4 * Dc && !align_corners && Dc >= ds) {
+  if (up && D == 4 * Dc && !align_corners && Dc >= ds) {
     if (ds == 4) hipLaunchKernelGGL(soft_argmin_up4_kernel<4>, grid, block, 0, s, p);
     else if (ds == 2) hipLaunchKernelGGL(soft_argmin_up4_kernel<2>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(soft_argmin_up4_kernel<1>, grid, block, 0, s, p);

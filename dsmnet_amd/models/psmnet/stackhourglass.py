@@ -102,7 +102,8 @@ class PSMNet(nn.Module):
         """Eval mode without autograd: the 32-channel full-resolution layers (dres0, dres1,
         classif*.0 -- 82 % of the trunk's FLOPs) run on the z-sliding S3 kernel, their inputs
         handed over pre-split by the layer before."""
-        return cv.get_option("s3") and not self.training and not torch.is_grad_enabled()
+        return (cv.get_option("s3") and cv.get_option_bf16x3() and not self.training and
+                not torch.is_grad_enabled())
 
     def regularise(self, cost):
         """3-D trunk (stackhourglass.py:135-149): volume -> the three head costs.  ``cost``: the

@@ -153,7 +153,14 @@ typedef struct dsm_conv3d_args {
    * dsm_conv_pack_weights_s3in.  The operand split then happened once, in the producer's
    * epilogue, and the kernel's staging is a plain copy. */
   const void*  x_s3;
+  /* ABI v4: tuning / A-B switches of THIS call (0 = the plan's own choice).  The library reads no
+   * environment variable and holds no global switch: a plan is a pure function of the arguments. */
+  int          flags;
 } dsm_conv3d_args;
+#define DSM_CONV_FP32_MFMA      0x1      /* keep the layer on the exact fp32-input MFMA (no bf16x3)   */
+#define DSM_CONV_COUT1_CHUNKED  0x2      /* Cout = 1: the chunked kernel instead of the z-sliding one */
+#define DSM_CONV_TM_SHIFT       4        /* bits 4..7: force the tile height 4*TM rows (TM = 1, 2, 4) */
+#define DSM_CONV_BLOCKS_SHIFT   16       /* bits 16..31: force the persistent grid size               */
 
 /* bytes of the packed (MFMA-fragment-ordered) weight buffer */
 size_t dsm_conv3d_packed_weight_bytes(int Cin, int Cout, int transposed);

@@ -10,7 +10,7 @@ tag, stats_csv, bench_json, prof_json = sys.argv[1:5]
 bench = json.load(open(bench_json))
 prof = json.load(open(prof_json))
 rows = list(csv.DictReader(open(stats_csv)))
-OURS = ("conv3d_mfma", "conv_bf16x3", "deconv_bf16x3", "deconv3d", "cout1", "soft_argmin", "volume_", "pack_weights", "spp_", "corr1d", "warp_")
+OURS = ("conv3d_mfma", "conv_bf16x3", "deconv_bf16x3", "deconv3d", "cout1", "soft_argmin", "volume_", "pack_weights", "spp_", "corr1d", "warp_", "conv_s3", "feat_s3", "s3_from", "s3_to", "bn_")
 
 
 def short(n):
@@ -25,7 +25,9 @@ def plan_name(n):
         S, NT, TM, CK, KZ, K, DIL = map(int, m.groups())
         return ("conv3d_mfma_kernel<S=%d,NT=%d,TM=%d,CK=%d>" % (S, NT, TM, CK) if KZ == 3 else
                 "conv2d_mfma_kernel<S=%d,NT=%d,TM=%d,K=%d,DIL=%d>" % (S, NT, TM, K, DIL))
-    m = re.match(r"conv_bf16x3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", n)
+    if n.startswith("conv_s3_kernel"):
+        return "conv3d_s3_bf16x3_mfma_kernel"
+    m = re.match(r"conv_bf16x3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:false|true))?>", n)
     if m:
         NT, TM, KZ, DIL, S = map(int, m.groups())
         if S == 2:
@@ -39,14 +41,14 @@ def plan_name(n):
     if m:
         return "deconv3d_mfma_kernel<NT=%s,CK=%s>" % m.groups()
     n = re.sub(r"<.*$", "", n)
-    return {"soft_argmin_up4_kernel": "soft_argmin_fwd_kernel"}.get(n, n)
+    return n
 
 
 total = sum(float(r["TotalDurationNs"]) for r in rows)
 ours = [r for r in rows if any(k in r["Name"] for k in OURS)]
 ours_total = sum(float(r["TotalDurationNs"]) for r in ours)
 roofs = bench.get("rooflines", {})
-print("# Round 1, run %s — `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline`\n" % tag.upper())
+print("# Run %s — `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline`\n" % tag.upper())
 print("PSMNet D=192, 384x1280, 1 MI355X.  Un-profiled bench line (`%s_bench.json`): **%.1f pairs/s**, %.2f ms/step (%s);"
       % (tag, bench["value"], bench["ms_per_step"], bench["config"].get("launch", "eager launches")))
 cb = bench.get("cpu_baseline")
@@ -66,6 +68,10 @@ print("\nDominant kernel `%s`: %.1f %s = %.1f %% of the %.1f peak (%d launches/s
 if "bf16_mfma_tflops_executed" in d:
     print("That peak is the dense bf16 MFMA peak (%.0f TF/s) / 6 MFMAs per fp32 product; executed bf16 MFMA rate %.0f TF/s; "
           "%.2fx the fp32-input MFMA peak (157.3 TF/s) in algorithmic fp32 FLOP/s." % (d["bf16_mfma_peak"], d["bf16_mfma_tflops_executed"], d["x_fp32_mfma_peak"]))
+v = bench.get("cost_volume_build")
+if v:
+    print("Cost-volume build (standalone; the default forward no longer launches it): %.1f us after a tower pass -> %.0f GB/s = %.1f %% of 8 TB/s (north-star target >= 60 %%); back to back %.1f us = %.1f %%; %.1f MB algorithmic."
+          % (v["in_sequence_us"], v["in_sequence"], 100 * v["in_sequence_frac"], v["back_to_back_us"], 100 * v["back_to_back_frac"], v["algorithmic_bytes"] / 1e6))
 v = roofs.get("volume_ndhwc_fwd_kernel")
 if v:
     print("Cost-volume build: %.1f us by in-bench events -> %.0f GB/s = %.1f %% of 8 TB/s (north-star target >= 60 %%), %.1f %% of the 6.29 TB/s copy ceiling; PMC traffic %.1f MB vs %.1f MB algorithmic (profiles/r01_d_pmc.md)."
