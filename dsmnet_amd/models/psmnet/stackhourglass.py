@@ -61,12 +61,21 @@ class hourglass(nn.Module):
 
 
 class PSMNet(nn.Module):
-    def __init__(self, maxdisp=192):
+    """``PSMNet(maxdisp)`` as the reference; ``align_corners`` (extra, default False) selects the
+    interpolation convention of every upsampling on the path -- the SPP branches and the trilinear
+    upsampling fused into the soft-argmin heads.  The reference calls ``F.upsample`` without the
+    argument (stackhourglass.py:152-166, submodule.py:126-137): that resolves to
+    ``align_corners=False`` on torch >= 0.4.1 (the oracle and the goldens) and meant ``True`` on the
+    PyTorch 0.3 the reference was written for -- pass ``True`` to run a checkpoint the way its
+    authors ran it ("version drift")."""
+
+    def __init__(self, maxdisp=192, align_corners=False):
         super(PSMNet, self).__init__()
         self.name = "psmnet"
         self.maxdisp = maxdisp
+        self.align_corners = bool(align_corners)
         self.count_levels = 1
-        self.feature_extraction = feature_extraction()
+        self.feature_extraction = feature_extraction(align_corners=align_corners)
         relu = lambda: nn.ReLU(inplace=True)  # noqa: E731
         self.dres0 = Chain3d(convbn_3d(64, 32, 3, 1, 1), relu(), convbn_3d(32, 32, 3, 1, 1), relu())
         self.dres1 = Chain3d(convbn_3d(32, 32, 3, 1, 1), relu(), convbn_3d(32, 32, 3, 1, 1))
@@ -147,7 +156,7 @@ class PSMNet(nn.Module):
             cost = cv.concat_volume(refimg_fea, targetimg_fea, self.maxdisp // 4, mask_left=True)
         cost1, cost2, cost3 = self.regularise(cost)
         size = (self.maxdisp, left.shape[2], left.shape[3])
-        pred1 = cv.soft_argmin(cost1, size)
-        pred2 = cv.soft_argmin(cost2, size)
-        pred3 = cv.soft_argmin(cost3, size)
+        pred1 = cv.soft_argmin(cost1, size, align_corners=self.align_corners)
+        pred2 = cv.soft_argmin(cost2, size, align_corners=self.align_corners)
+        pred3 = cv.soft_argmin(cost3, size, align_corners=self.align_corners)
         return [0, 0, 0], [pred3, pred2, pred1]

@@ -81,8 +81,9 @@ class feature_extraction(nn.Module):
     the MFMA kernel (blocks2d) and the SPP head in three launches (csrc/spp.hip); training and
     CPU tensors take the stock torch layers."""
 
-    def __init__(self):
+    def __init__(self, align_corners=False):
         super(feature_extraction, self).__init__()
+        self.align_corners = bool(align_corners)   # of the SPP branches' bilinear upsampling
         self.inplanes = 32
         stem = []
         for cin, stride in ((3, 2), (32, 1), (32, 1)):
@@ -123,7 +124,7 @@ class feature_extraction(nn.Module):
             pooled = F.avg_pool2d(pooled, 8 if i == 4 else 2)
             branch = getattr(self, "branch%d" % i)
             y = branch[1](pooled, relu=True)          # convbn + ReLU ([0] is the AvgPool2d)
-            pyramid.append(F.interpolate(y, size=size, mode="bilinear", align_corners=False))
+            pyramid.append(F.interpolate(y, size=size, mode="bilinear", align_corners=self.align_corners))
         return torch.cat([raw, skip] + pyramid, dim=1)
 
     def _spp_params(self):
@@ -171,7 +172,7 @@ class feature_extraction(nn.Module):
             x = self.layer1(x)
             raw = self.layer2(x)
             skip = self.layer4(self.layer3(raw))
-        if skip.is_cuda and not self.training and not torch.is_grad_enabled():
+        if skip.is_cuda and not self.training and not torch.is_grad_enabled() and not self.align_corners:
             x = cv.spp_head(raw, skip, *self._spp_params())       # three launches (csrc/spp.hip)
         else:
             x = self._spp_stock(raw, skip)

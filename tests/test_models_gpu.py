@@ -326,3 +326,40 @@ def test_gcnet_feature2d_runs_on_the_hip_kernels(hip_lib, golden_e2e):
         want = OM.gcnet_features(OM.Net(sd), imL)
     assert got.shape == want.shape and got.is_contiguous()
     assert maxerr(got, want) <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_psmnet_align_corners_switch(hip_lib, golden_e2e):
+    """``PSMNet(maxdisp, align_corners=True)`` -- the PyTorch-0.3 meaning of the reference's
+    ``F.upsample`` calls: every upsampling on the path switches convention
+    (SPP branches, the trilinear upsampling fused into the heads), checked against the oracle's
+    stages evaluated with the same convention."""
+    import torch.nn.functional as TF
+    from oracle import ops as OO
+    from dsmnet_amd.models.psmnet.stackhourglass import PSMNet
+    sd, cfg = golden_state(golden_e2e, "psmnet")
+    imL, imR = images(cfg["image_seed"], *cfg["hw"])
+    m = PSMNet(192, align_corners=True)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    orig = TF.interpolate
+
+    def interp_true(x, *a, **k):                    # the oracle's SPP branches with align_corners=True
+        if k.get("mode") == "bilinear":
+            k["align_corners"] = True
+        return orig(x, *a, **k)
+
+    with torch.no_grad():
+        _, got = m(imL.cuda(), imR.cuda())
+        TF.interpolate = interp_true
+        try:
+            n = OM.Net(sd)
+            fl, fr = OM.psmnet_features(n, imL), OM.psmnet_features(n, imR)
+        finally:
+            TF.interpolate = orig
+        costs = OM.psmnet_trunk(n, OO.concat_volume(fl, fr, 48, True))
+        want = [OO.soft_argmin(c, (192,) + tuple(cfg["hw"]), align_corners=True)
+                for c in (costs[2], costs[1], costs[0])]
+        _, default = load("psmnet", sd)(imL.cuda(), imR.cuda())
+    for g, w in zip(got, want):
+        assert maxerr(g, w) <= DISP_TOL
+    assert maxerr(got[0], default[0]) > 10 * DISP_TOL          # the two conventions really differ
