@@ -60,9 +60,12 @@ class feature3d(nn.Module):
         self.l37 = deconv3d_bn(F_, 1, kernel_size=3, stride=2, bn=False, activefun=None)
         self.softmax = nn.Softmax2d()          # parameter-free; kept for attribute parity
 
-    def cost(self, x):
+    def cost(self, x, virtual=None):
         """x18 -> x37, the (B,1,2D,2h,2w) cost.  Skip additions are fused into the
-        transposed convolutions (relu(bn(deconv)) + skip, cropped: gcnet.py:78-96)."""
+        transposed convolutions (relu(bn(deconv)) + skip, cropped: gcnet.py:78-96).
+        ``virtual``: the same volume as a never-materialised ``S3Volume`` (eval): l19 (64 -> 32)
+        then stages it from the split feature maps on the z-sliding kernel and hands l20 its
+        result pre-split; the fp32 volume ``x`` still feeds the stride-2 l21."""
         x21 = self.l21(x)
         x24 = self.l24(x21)
         x27 = self.l27(x24)
@@ -70,12 +73,16 @@ class feature3d(nn.Module):
         x33 = self.l33(x32, residual=self.l29(self.l28(x27)))
         x34 = self.l34(x33, residual=self.l26(self.l25(x24)))
         x35 = self.l35(x34, residual=self.l23(self.l22(x21)))
-        x36 = self.l36(x35, residual=self.l20(self.l19(x)))
+        if virtual is not None and self.l19.eats_s3() and self.l20.eats_s3():
+            x20 = self.l20(self.l19(virtual, out="s3"))
+        else:
+            x20 = self.l20(self.l19(x))
+        x36 = self.l36(x35, residual=x20)
         return self.l37(x36)
 
-    def forward(self, x, mode="train"):
+    def forward(self, x, mode="train", virtual=None):
         # `mode="test"` only frees intermediates early in the reference; nothing to do here
-        return cv.soft_argmin(self.cost(x), None, negate=True).unsqueeze(1)
+        return cv.soft_argmin(self.cost(x, virtual), None, negate=True).unsqueeze(1)
 
 
 class gcnet(nn.Module):
@@ -99,5 +106,9 @@ class gcnet(nn.Module):
             raise ValueError("gcnet: imL and imR must have the same shape")   # gcnet.py:127
         fL, fR = self.features(imL, imR)
         xL = cv.concat_volume(fL, fR, self.D, mask_left=False)
-        oL = self.layer3d(xL, mode)[:, :, : imL.shape[-2], : imL.shape[-1]]
+        virtual = None
+        if (cv.get_option("s3") and cv.get_option("fuse_volume") and cv.get_option_bf16x3()
+                and not self.training and not torch.is_grad_enabled() and fL.shape[1] % 32 == 0):
+            virtual = cv.concat_volume_s3(fL, fR, self.D, False, materialise=False)
+        oL = self.layer3d(xL, mode, virtual)[:, :, : imL.shape[-2], : imL.shape[-1]]
         return [0], [oL]
