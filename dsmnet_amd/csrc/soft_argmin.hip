@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256) void soft_argmin_fwd_kernel(SaParams p) {
 //   v(4k+0) = .375 P[k-1] + .625 P[k]     v(4k+1) = .125 P[k-1] + .875 P[k]
 //   v(4k+2) = .875 P[k]   + .125 P[k+1]   v(4k+3) = .625 P[k]   + .375 P[k+1]
 // with P[-1] := P[0], P[Dc] := P[Dc-1] (the clamps), P[k] the pixel's bilinear sample of
-// coarse plane k.  No per-bin index arithmetic; an exact two-pass softmax (pass 1: max of
-// the fine values, pass 2: one v_exp per bin) replaces the branchy online update.
+// coarse plane k.  No per-bin index arithmetic; one pass with a per-PLANE running maximum (see
+// the loop) replaces both the branchy per-bin online update and r01's exact two-pass form.
 template <int DSPLIT>
 __global__ __launch_bounds__(256) void soft_argmin_up4_kernel(SaParams p) {
   constexpr int PXW = DSM_WAVE / DSPLIT;
@@ -156,23 +156,21 @@ __global__ __launch_bounds__(256) void soft_argmin_up4_kernel(SaParams p) {
     const long ps = (long)p.Hc * p.Wc;
     const float* base = p.cost + (long)b * p.Dc * ps;
     const float sg = p.sign;
-    // pass 1: exact maximum of the fine values of this segment
+    // ONE pass (r02; the r01 kernel evaluated every bilinear sample and lerp twice: an exact-max
+    // pass, then the sums).  Every fine value of coarse interval k is a convex combination of
+    // P[k-1], P[k], P[k+1], so the running maximum of the P's seen so far -- taken BEFORE interval
+    // k is summed, P[k+1] included -- bounds every exponent by 0: the sums are rescaled by
+    // exp(m_old - m_new) whenever a larger P arrives (one extra v_exp per plane, 5 instead of
+    // 4 + a second sampling pass).  Mathematically the softmax is shift-invariant; numerically
+    // each rescale costs one rounding of l and sum, and it happens O(log Dc) times on average.
     float Pm = sg * plane_at(base, ps, max(k_lo - 1, 0), st);
     float Pc = sg * plane_at(base, ps, k_lo, st);
-    float m = -INFINITY;
+    float m = fmaxf(Pm, Pc), l = 0.f, sum = 0.f;
     for (int k = k_lo; k < k_hi; ++k) {
       const float Pn = sg * plane_at(base, ps, min(k + 1, p.Dc - 1), st);
-      const float v0 = 0.375f * Pm + 0.625f * Pc, v1 = 0.125f * Pm + 0.875f * Pc;
-      const float v2 = 0.875f * Pc + 0.125f * Pn, v3 = 0.625f * Pc + 0.375f * Pn;
-      m = fmaxf(m, fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
-      Pm = Pc; Pc = Pn;
-    }
-    // pass 2: sums
-    Pm = sg * plane_at(base, ps, max(k_lo - 1, 0), st);
-    Pc = sg * plane_at(base, ps, k_lo, st);
-    float l = 0.f, sum = 0.f;
-    for (int k = k_lo; k < k_hi; ++k) {
-      const float Pn = sg * plane_at(base, ps, min(k + 1, p.Dc - 1), st);
+      const float mn = fmaxf(m, Pn);
+      const float rs = __expf(m - mn);                     // 1 when the maximum stands
+      l *= rs; sum *= rs; m = mn;
       const float d0 = (float)(4 * k);
       const float e0 = __expf(0.375f * Pm + 0.625f * Pc - m);
       const float e1 = __expf(0.125f * Pm + 0.875f * Pc - m);
@@ -182,6 +180,37 @@ __global__ __launch_bounds__(256) void soft_argmin_up4_kernel(SaParams p) {
       sum = fmaf(d0, e0, sum); sum = fmaf(d0 + 1.f, e1, sum);
       sum = fmaf(d0 + 2.f, e2, sum); sum = fmaf(d0 + 3.f, e3, sum);
       Pm = Pc; Pc = Pn;
+    }
+    // Guard: the running maximum of the P's can exceed every FINE value by more than the range
+    // of expf (an isolated peak of height h leaves 0.875 h as the largest fine value): all terms
+    // then underflow.  Such a segment (l tiny or zero) is redone with the exact maximum of its
+    // fine values -- the r01 two-pass form; rare, and only ill-conditioned costs reach it.
+    if (!(l > 1e-30f)) {
+      Pm = sg * plane_at(base, ps, max(k_lo - 1, 0), st);
+      Pc = sg * plane_at(base, ps, k_lo, st);
+      m = -INFINITY;
+      for (int k = k_lo; k < k_hi; ++k) {
+        const float Pn = sg * plane_at(base, ps, min(k + 1, p.Dc - 1), st);
+        const float v0 = 0.375f * Pm + 0.625f * Pc, v1 = 0.125f * Pm + 0.875f * Pc;
+        const float v2 = 0.875f * Pc + 0.125f * Pn, v3 = 0.625f * Pc + 0.375f * Pn;
+        m = fmaxf(m, fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
+        Pm = Pc; Pc = Pn;
+      }
+      Pm = sg * plane_at(base, ps, max(k_lo - 1, 0), st);
+      Pc = sg * plane_at(base, ps, k_lo, st);
+      l = 0.f; sum = 0.f;
+      for (int k = k_lo; k < k_hi; ++k) {
+        const float Pn = sg * plane_at(base, ps, min(k + 1, p.Dc - 1), st);
+        const float d0 = (float)(4 * k);
+        const float e0 = __expf(0.375f * Pm + 0.625f * Pc - m);
+        const float e1 = __expf(0.125f * Pm + 0.875f * Pc - m);
+        const float e2 = __expf(0.875f * Pc + 0.125f * Pn - m);
+        const float e3 = __expf(0.625f * Pc + 0.375f * Pn - m);
+        l += (e0 + e1) + (e2 + e3);
+        sum = fmaf(d0, e0, sum); sum = fmaf(d0 + 1.f, e1, sum);
+        sum = fmaf(d0 + 2.f, e2, sum); sum = fmaf(d0 + 3.f, e3, sum);
+        Pm = Pc; Pc = Pn;
+      }
     }
     acc.m = m; acc.l = l; acc.s = sum;
   }

@@ -162,3 +162,21 @@ def test_softargmin_full_size_properties(cv):
     assert maxerr(cv.soft_argmin(c + 3.0, (192, 384, 1280)), out) <= 2e-3
     flat = cv.soft_argmin(torch.zeros_like(c), (192, 384, 1280))
     assert maxerr(flat, torch.full_like(flat, 95.5)) <= 1e-3
+
+
+def test_soft_argmin_up4_isolated_peaks_force_the_exact_fallback(hip_lib):
+    """The x4 head sums in ONE pass under a running maximum of the coarse samples; an isolated peak
+    of height >> 88 leaves every fine value more than expf's range below that maximum, and the
+    pixel is then redone with the exact two-pass form.  Costs that force the branch on most pixels
+    (peaks of height 300..3000, one-hot softmax), plus moderate ones that never take it."""
+    from dsmnet_amd import costvolume as cv
+    from oracle import ops as OO
+    g = torch.Generator().manual_seed(5)
+    for scale in (1.0, 300.0, 3000.0):
+        cost = torch.randn(1, 1, 12, 9, 17, generator=g)
+        peaks = torch.randint(0, 12, (9, 17), generator=g)
+        cost[0, 0].scatter_(0, peaks.unsqueeze(0), scale * (1.0 + torch.rand(1, 9, 17, generator=g)))
+        want = OO.soft_argmin(cost, (48, 36, 68))
+        got = cv.soft_argmin(cost.cuda(), (48, 36, 68))
+        assert torch.isfinite(got).all()
+        assert (got.cpu() - want).abs().max().item() <= 1e-3, scale
