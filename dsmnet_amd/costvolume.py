@@ -918,3 +918,46 @@ class BnAddRelu3dFunction(torch.autograd.Function):
 def bn_add_relu3d(y, gamma, beta, residual, running_mean, running_var, relu, momentum, eps):
     return BnAddRelu3dFunction.apply(y, gamma, beta, residual, running_mean, running_var, int(relu),
                                      float(momentum), float(eps))
+
+
+# ----------------------------------------------------------------------------
+# decoder level of DispNetC / iResNet: deconv bias + ReLU + x2 upsampling + myCat2d, one launch
+# ----------------------------------------------------------------------------
+def decoder_level(deconv, x, pr, skip):
+    """``myCat2d(deconv(x), upsample(pr), skip)`` of the reference's decoders
+    (models/dispnetcorr.py:89-132, models/iresnet.py:119-161,186-193; util_fun.py:7-15) with
+    ``deconv`` = ``Sequential(ConvTranspose2d(bias), ReLU)`` or a bare ``ConvTranspose2d``.
+    Eval mode on the GPU: the transposed convolution runs without its bias (stock kernel) and ONE
+    launch does bias + ReLU + bilinear x2 upsampling of ``pr`` + the crops + the concatenation;
+    otherwise (training, autograd, CPU) the stock ops."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    conv = deconv[0] if isinstance(deconv, nn.Sequential) else deconv
+    relu = isinstance(deconv, nn.Sequential) and len(deconv) > 1
+    fast = (x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32 and
+            isinstance(conv, nn.ConvTranspose2d) and
+            (not relu or (len(deconv) == 2 and isinstance(deconv[1], nn.ReLU))))
+    if not fast:
+        seq = [deconv(x)]
+        if pr is not None:
+            seq.append(F.interpolate(pr, scale_factor=2, mode="bilinear", align_corners=False))
+        if skip is not None:
+            seq.append(skip)
+        h = min(t.shape[2] for t in seq)
+        w = min(t.shape[3] for t in seq)
+        return torch.cat([t[:, :, :h, :w] for t in seq], dim=1)
+    up = F.conv_transpose2d(x, conv.weight, None, conv.stride, conv.padding, conv.output_padding,
+                            conv.groups, conv.dilation).contiguous()
+    B, Cu, Hu, Wu = up.shape
+    pr = None if pr is None else pr.contiguous()
+    skip = None if skip is None else skip.contiguous()
+    Cp, Hp, Wp = (0, 0, 0) if pr is None else pr.shape[1:]
+    Cs, Hs, Ws = (0, 0, 0) if skip is None else skip.shape[1:]
+    h = min([Hu] + ([2 * Hp] if Cp else []) + ([Hs] if Cs else []))
+    w = min([Wu] + ([2 * Wp] if Cp else []) + ([Ws] if Cs else []))
+    out = torch.empty((B, Cu + Cp + Cs, h, w), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device), _timed("decoder_cat_kernel", 8.0 * out.numel()):
+        rc = _lib.load().dsm_decoder_cat(_p(up), _p(conv.bias), _p(pr), _p(skip), _p(out), B, Cu, Cp, Cs,
+                                         Hu, Wu, Hp, Wp, Hs, Ws, int(relu), _stream())
+    _lib.check(rc, "dsm_decoder_cat")
+    return out

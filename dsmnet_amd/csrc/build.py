@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["abi.hip", "corr1d.hip", "cost_volume.hip", "soft_argmin.hip", "conv3d.hip",
-           "conv3d_bwd.hip", "conv_s3.hip", "bn3d.hip", "spp.hip", "warp.hip"]
+           "conv3d_bwd.hip", "conv_s3.hip", "bn3d.hip", "decoder.hip", "spp.hip", "warp.hip"]
 LIB = os.path.join(HERE, "libdsmnet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

@@ -1,9 +1,11 @@
 """DispNetC on the MI355X cost-volume path: same names, attribute tree and return convention
 as models/dispnetcorr.py; `self.corr` is the HIP Corr1d (D=41), everything else is the
-reference's 2-D encoder/decoder in stock torch layers (outside the hot path)."""
+reference's 2-D encoder/decoder; each decoder level's bias + ReLU + upsampling + myCat2d is one
+HIP launch in eval mode (`costvolume.decoder_level`, csrc/decoder.hip)."""
 import torch
 import torch.nn as nn
 
+from .. import costvolume as cv
 from .util_conv import Corr1d, conv2d_bn, deconv2d_bn, net_init
 from .util_fun import myCat2d
 
@@ -61,8 +63,9 @@ class dispnetcorr(nn.Module):
         pr = self.pr6(x)
         out, out_scale = [pr], [6]
         for lvl in (5, 4, 3, 2, 1):
-            up = getattr(self, "deconv%d" % lvl)(x)
-            x = getattr(self, "iconv%d" % lvl)(myCat2d(up, self.upsample(pr), skips[lvl]))
+            # myCat2d(deconv(x), upsample(pr), skip): dispnetcorr.py:94-95 and the levels below
+            x = getattr(self, "iconv%d" % lvl)(
+                cv.decoder_level(getattr(self, "deconv%d" % lvl), x, pr, skips[lvl]))
             pr = getattr(self, "pr%d" % lvl)(x)
             out.insert(0, pr)
             out_scale.insert(0, lvl)

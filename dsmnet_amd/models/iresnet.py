@@ -106,8 +106,8 @@ class iresnet(nn.Module):
         pr = self.pr6(x)
         out, out_scale, keep = [pr], [6], {}
         for lvl in (5, 4, 3, 2, 1, 0):
-            up = getattr(self, "deconv%d" % lvl)(x)
-            x = getattr(self, "iconv%d" % lvl)(myCat2d(up, self.upsample(pr), skips[lvl]))
+            x = getattr(self, "iconv%d" % lvl)(
+                cv.decoder_level(getattr(self, "deconv%d" % lvl), x, pr, skips[lvl]))
             pr = getattr(self, "pr%d" % lvl)(x)
             keep[lvl] = pr
             out.insert(0, pr)
@@ -128,13 +128,11 @@ class iresnet(nn.Module):
             r_res2 = self.r_res2(r_conv2_1)
             r_pr2 = r_pr2 + r_res2
             out.insert(0, r_pr2); out_scale.insert(0, 2)
-            r_iconv1 = self.r_iconv1(myCat2d(self.r_deconv1(r_conv2_1), self.upsample(r_res2),
-                                             r_conv1_1))
+            r_iconv1 = self.r_iconv1(cv.decoder_level(self.r_deconv1, r_conv2_1, r_res2, r_conv1_1))
             r_res1 = self.r_res1(r_iconv1)
             r_pr1 = r_pr1 + r_res1
             out.insert(0, r_pr1); out_scale.insert(0, 1)
-            r_iconv0 = self.r_iconv0(myCat2d(self.r_deconv0(r_iconv1), self.upsample(r_res1),
-                                             r_conv0))
+            r_iconv0 = self.r_iconv0(cv.decoder_level(self.r_deconv0, r_iconv1, r_res1, r_conv0))
             r_pr0 = r_pr0 + self.r_res0(r_iconv0)
             out.insert(0, r_pr0); out_scale.insert(0, 0)
         if mode == "test":

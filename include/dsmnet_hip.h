@@ -350,6 +350,16 @@ int dsm_spp_concat(const void* raw, const void* skip, const void* branches, void
 int dsm_warp_abs_error(const void* L, const void* R, const void* disp, void* out, int B, int C,
                        int H, int W, int H0, int W0, float delt, dsm_stream_t stream);
 
+/* One decoder level of DispNetC / iResNet (models/dispnetcorr.py:89-132, iresnet.py:119-161,186-193):
+ *   out = myCat2d( relu?(up + bias), upsample_x2_bilinear(pr), skip )      (util_fun.py:7-15)
+ * up (B,Cu,Hu,Wu): the transposed convolution's output WITHOUT its bias; bias [Cu] or NULL;
+ * pr (B,Cp,Hp,Wp) or NULL (Cp = 0); skip (B,Cs,Hs,Ws) or NULL (Cs = 0); all NCHW fp32.
+ * out (B, Cu+Cp+Cs, h, w) with h = min(Hu, 2 Hp, Hs), w = min(Wu, 2 Wp, Ws) -- the caller
+ * allocates it from those rules.  align_corners = False (what nn.Upsample resolves to today). */
+int dsm_decoder_cat(const void* up, const void* bias, const void* pr, const void* skip, void* out,
+                    int B, int Cu, int Cp, int Cs, int Hu, int Wu, int Hp, int Wp, int Hs, int Ws,
+                    int relu, dsm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

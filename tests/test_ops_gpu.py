@@ -180,3 +180,33 @@ def test_soft_argmin_up4_isolated_peaks_force_the_exact_fallback(hip_lib):
         got = cv.soft_argmin(cost.cuda(), (48, 36, 68))
         assert torch.isfinite(got).all()
         assert (got.cpu() - want).abs().max().item() <= 1e-3, scale
+
+
+@pytest.mark.parametrize("relu,shapes", [
+    (True, ((2, 24, 13, 22), (1, 6, 11), (16, 12, 21))),     # ragged: every operand a different size
+    (True, ((1, 32, 16, 40), (1, 8, 20), (64, 16, 40))),
+    (False, ((1, 8, 10, 12), None, (4, 10, 12))),            # bare deconv, no prediction map
+    (True, ((1, 8, 10, 12), (2, 5, 6), None)),               # no skip
+])
+def test_decoder_level_equals_the_stock_ops(hip_lib, relu, shapes):
+    """``costvolume.decoder_level`` (csrc/decoder.hip) = myCat2d(deconv(x), upsample(pr), skip) of
+    models/dispnetcorr.py:89-132: copies bit-identical, the upsampled channel to 1e-6."""
+    import torch.nn as nn
+    from dsmnet_amd import costvolume as cv
+    (B, Cu, Hu, Wu), prs, sks = shapes
+    torch.manual_seed(3)
+    conv = nn.ConvTranspose2d(12, Cu, 4, 2, 1, bias=True)
+    deconv = (nn.Sequential(conv, nn.ReLU(inplace=True)) if relu else conv).cuda()
+    x = torch.randn(B, 12, Hu // 2, Wu // 2, device="cuda")
+    pr = None if prs is None else torch.randn(B, *prs, device="cuda")
+    skip = None if sks is None else torch.randn(B, *sks, device="cuda")
+    with torch.no_grad():
+        got = cv.decoder_level(deconv, x, pr, skip)
+    with torch.enable_grad():                                   # the stock branch
+        want = cv.decoder_level(deconv, x.clone().requires_grad_(True), pr, skip).detach()
+    assert got.shape == want.shape
+    Cu_, Cp = Cu, (0 if pr is None else pr.shape[1])
+    assert torch.equal(got[:, :Cu_], want[:, :Cu_])
+    assert torch.equal(got[:, Cu_ + Cp:], want[:, Cu_ + Cp:])
+    if Cp:
+        assert (got[:, Cu_:Cu_ + Cp] - want[:, Cu_:Cu_ + Cp]).abs().max().item() <= 1e-6
