@@ -151,6 +151,26 @@ def corr1d(fL, fR, D, stride=1, kernel_size=1):
 # ----------------------------------------------------------------------------
 # (a2, a3) concatenation cost volume
 # ----------------------------------------------------------------------------
+def concat_volume_right(fL, fR, D):
+    """The right-referenced volume of ``gcnet_LR`` (models/gcnet.py:155-164), (B, 2C, D, H, W)
+    channels_last_3d: right features at every x, ``vol[:, C:, d, y, x] = fL[y, x + d]`` for
+    ``x + d < W``.  Same kernel as ``concat_volume`` walking the other way.  Inference only."""
+    _require_device("concat_volume_right", fL, fR)
+    _same_shape("concat_volume_right", fL, fR)
+    if fL.requires_grad or fR.requires_grad:
+        if torch.is_grad_enabled():
+            raise NotImplementedError("concat_volume_right has no backward (gcnet_LR is not reachable "
+                                      "from the reference's model factory)")
+    fL, fR = fL.contiguous(), fR.contiguous()
+    B, C, H, W = fL.shape
+    vol = torch.empty((B, 2 * C, D, H, W), device=fL.device, dtype=fL.dtype, memory_format=_CL3D)
+    with torch.cuda.device(fL.device), _timed("volume_ndhwc_fwd_kernel", 4.0 * (2 * B * C * H * W + 2 * B * C * D * H * W)):
+        rc = _lib.load().dsm_concat_volume_fwd(_p(fR), _p(fL), _p(vol), B, C, H, W, int(D), 2,
+                                               _lib.DSM_NDHWC, _lib.DSM_F32, _stream())
+    _lib.check(rc, "dsm_concat_volume_fwd")
+    return vol
+
+
 class ConcatVolumeFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fL, fR, D, mask_left, channels_last):

@@ -27,6 +27,11 @@ __global__ __launch_bounds__(256) void volume_ndhwc_fwd_kernel(
   float* Rs = lds + TX * pitch;            // [nR][pitch], column j <-> x = x0-(D-1)+j
   const int x0 = blockIdx.x * TX, y = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x;
+  // bit 1 of mask_left: the RIGHT-referenced volume of gcnet_LR (models/gcnet.py:155-164): the
+  // caller passes (fR, fL) as (first, second); the second map is then read at x + d (zero for
+  // x + d >= W) instead of x - d, i.e. the staged window starts at x0 and the walk goes forward
+  const bool rightref = (mask_left & 2) != 0;
+  mask_left &= 1;
   const long rowL = ((long)b * C * H + y) * W;      // + c*H*W + x
   const long cstride = (long)H * W;
   // stage + transpose (global reads coalesced along x)
@@ -36,7 +41,7 @@ __global__ __launch_bounds__(256) void volume_ndhwc_fwd_kernel(
   }
   for (int c = tid >> 6; c < C; c += 4) {
     for (int j = tid & 63; j < nR; j += 64) {
-      const int x = x0 - (D - 1) + j;
+      const int x = rightref ? x0 + j : x0 - (D - 1) + j;
       Rs[j * pitch + c] = (x >= 0 && x < W) ? fR[rowL + c * cstride + x] : 0.f;
     }
   }
@@ -52,15 +57,16 @@ __global__ __launch_bounds__(256) void volume_ndhwc_fwd_kernel(
     if (c4 < q) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(&Ls[t * pitch + c4 * 4]);
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const int dfull = mask_left ? min(D, x + 1) : D;     // planes with x >= d
+      const int dfull = mask_left ? (rightref ? min(D, W - x) : min(D, x + 1)) : D;     // planes with x >= d (x + d < W)
       for (int d = 0; d < dfull; ++d) *reinterpret_cast<f32x4*>(dst + d * plane) = v;
       for (int d = dfull; d < D; ++d) *reinterpret_cast<f32x4*>(dst + d * plane) = z;
     } else {
-      const float* src = &Rs[(t + D - 1) * pitch + (c4 - q) * 4];
+      const float* src = &Rs[(rightref ? t : t + D - 1) * pitch + (c4 - q) * 4];
+      const int step = rightref ? pitch : -pitch;
 #pragma unroll 4
-      for (int d = 0; d < D; ++d)          // columns with x-d < 0 were staged as zeros
+      for (int d = 0; d < D; ++d)          // columns outside [0, W) were staged as zeros
         *reinterpret_cast<f32x4*>(dst + d * plane) =
-            *reinterpret_cast<const f32x4*>(src - d * pitch);
+            *reinterpret_cast<const f32x4*>(src + d * step);
     }
   }
 }
@@ -218,6 +224,8 @@ extern "C" int dsm_concat_volume_fwd(const void* fL, const void* fR, void* vol, 
   const float* l = (const float*)fL;
   const float* r = (const float*)fR;
   float* v = (float*)vol;
+  DSM_REQUIRE((mask_left & ~3) == 0, DSM_ERR_ARG);
+  if (mask_left & 2) DSM_REQUIRE(layout == DSM_NDHWC, DSM_ERR_UNSUPPORTED);   // right-referenced: NDHWC forward only
   if (layout == DSM_NDHWC) {
     DSM_REQUIRE(C % 4 == 0, DSM_ERR_UNSUPPORTED);
     DSM_REQUIRE(dsm_aligned16(vol), DSM_ERR_ALIGN);

@@ -112,3 +112,26 @@ class gcnet(nn.Module):
             virtual = cv.concat_volume_s3(fL, fR, self.D, False, materialise=False)
         oL = self.layer3d(xL, mode, virtual)[:, :, : imL.shape[-2], : imL.shape[-1]]
         return [0], [oL]
+
+
+class gcnet_LR(nn.Module):
+    """The two-sided GCNet of models/gcnet.py:139-167: left- and right-referenced volumes through
+    the same trunk; ``forward(imL, imR) -> (oL, oR)``.  Not reachable from the reference's
+    ``model_create_by_name`` (nor from this one's); eval / inference only for the right side."""
+
+    def __init__(self, maxdisparity=192):
+        super(gcnet_LR, self).__init__()
+        self.name = "gcnet"
+        self.D = maxdisparity // 2
+        self.layer2d = feature2d(32)
+        self.layer3d = feature3d(32)
+        net_init(self)
+
+    def forward(self, imL, imR):
+        if imL.shape != imR.shape:
+            raise ValueError("gcnet_LR: imL and imR must have the same shape")   # gcnet.py:151
+        fL, fR = self.layer2d(imL), self.layer2d(imR)
+        xL = cv.concat_volume(fL, fR, self.D, mask_left=False)
+        xR = cv.concat_volume_right(fL, fR, self.D)
+        crop = (slice(None), slice(None), slice(0, imL.shape[-2]), slice(0, imL.shape[-1]))
+        return self.layer3d(xL)[crop], self.layer3d(xR)[crop]

@@ -72,6 +72,9 @@ int dsm_corr1d_bwd(const void* grad_out, const void* fL, const void* fR,
  *   vol[b,   c, d,y,x] = fL[b,c,y,x]        (x >= d, or every x when !mask_left)
  *   vol[b, C+c, d,y,x] = fR[b,c,y,x - d]    (x >= d)          zero elsewhere
  * fL, fR: (B,C,H,W); vol: (B,2C,D,H,W) in `layout`; written in one pass, no memset.
+ * mask_left bit 1 (ABI v4, NDHWC forward only): the right-referenced volume of gcnet_LR
+ * (models/gcnet.py:155-164) -- pass (fR, fL) as (fL, fR): the second map is read at x + d,
+ *   vol[b, C+c, d,y,x] = second[b,c,y,x + d]   (x + d < W), zero elsewhere.
  * ------------------------------------------------------------------------- */
 int dsm_concat_volume_fwd(const void* fL, const void* fR, void* vol,
                           int B, int C, int H, int W, int D,

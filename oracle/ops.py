@@ -68,6 +68,19 @@ def concat_volume(fL, fR, D, mask_left):
     return vol
 
 
+def concat_volume_right(fL, fR, D):
+    """The right-referenced volume of ``gcnet_LR``, ``models/gcnet.py:155-164`` (``xR``): the
+    RIGHT features fill every ``x`` of every disparity plane, the LEFT features are shifted the
+    other way -- ``xR[:, F:, d, :, x] = fL[:, :, :, x + d]`` for ``x < W - d``, zero beyond."""
+    B, C, H, W = fL.shape
+    vol = fL.new_zeros(B, 2 * C, D, H, W)
+    for d in range(D):
+        vol[:, :C, d] = fR
+        if d < W:
+            vol[:, C:, d, :, : W - d] = fL[..., d:]
+    return vol
+
+
 def crop_add(a, b):
     """Skip-add with crop to the common ``(d, h, w)``.
 

@@ -19,7 +19,7 @@ Decision recorded in the fixtures' metadata: ``F.upsample`` in this container
 (torch 2.10) resolves to ``align_corners=False``; the goldens therefore carry
 align_corners=False semantics ("Version drift").
 
-Usage:  python tests/golden/make_goldens.py [--only ops|blocks|e2e]
+Usage:  python tests/golden/make_goldens.py [--only ops|blocks|e2e|train|lr]
 """
 import argparse
 import json
@@ -464,14 +464,38 @@ def gen_train(store):
     print("  lr schedule, weight schedule: oracle == reference")
 
 
+def gen_lr(store):
+    """gcnet_LR's two-sided volume build, models/gcnet.py:155-164, executed from the file text
+    (``self.D`` is an int here: the Py2 ``maxdisparity/2`` of :143 is a float under Python 3)."""
+    print("G2b right-referenced volume (models/gcnet.py:155-164)")
+    src = ref_lines("models/gcnet.py", 155, 164).replace("Variable(", "(")
+    cases = []
+    for D, shp, seed in ((12, (1, 32, 6, 40), 31), (48, (2, 32, 5, 21), 32)):      # D > W in the second
+        fL, fR = seeded(seed, *shp), seeded(seed + 100, *shp)
+        me = _Self()
+        me.D = D
+        n, Fc, h, w = shp
+        ns = {"torch": torch, "self": me, "fL": fL, "fR": fR, "n": n, "F": Fc, "h": h, "w": w}
+        if D > w:       # the reference's slices fL[:, :, :, :-i] misbehave for i >= w (empty vs
+            continue    # negative wrap); the legal range is D <= W, which is what is pinned
+        exec(src, ns)
+        tag = "volume_lr.D%d.%s" % (D, "x".join(map(str, shp)))
+        check(tag + ".xL", ns["xL"], OO.concat_volume(fL, fR, D, False), 0.0)
+        check(tag + ".xR", ns["xR"], OO.concat_volume_right(fL, fR, D), 0.0)
+        put(store, tag + ".xR", ns["xR"], 2)
+        cases.append({"tag": tag, "D": D, "shape": list(shp), "seed": seed})
+    META["volume_lr_cases"] = cases
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["ops", "blocks", "e2e", "train"], default=None)
+    ap.add_argument("--only", choices=["ops", "blocks", "e2e", "train", "lr"], default=None)
     args = ap.parse_args()
     if not RL.available():
         raise SystemExit("needs the reference tree at %s (build container only)" % RL.REFERENCE_ROOT)
     torch.set_num_threads(os.cpu_count() or 1)
-    for part, fn in (("ops", gen_ops), ("blocks", gen_blocks), ("e2e", gen_e2e), ("train", gen_train)):
+    for part, fn in (("ops", gen_ops), ("blocks", gen_blocks), ("e2e", gen_e2e), ("train", gen_train),
+                     ("lr", gen_lr)):
         if args.only and args.only != part:
             continue
         store = {}

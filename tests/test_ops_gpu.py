@@ -210,3 +210,37 @@ def test_decoder_level_equals_the_stock_ops(hip_lib, relu, shapes):
     assert torch.equal(got[:, Cu_ + Cp:], want[:, Cu_ + Cp:])
     if Cp:
         assert (got[:, Cu_:Cu_ + Cp] - want[:, Cu_:Cu_ + Cp]).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("shape,D", [((1, 32, 6, 40), 12), ((2, 32, 5, 21), 9), ((1, 64, 3, 70), 48)])
+def test_right_referenced_volume_vs_oracle(hip_lib, shape, D):
+    """``concat_volume_right`` (gcnet_LR's xR, models/gcnet.py:155-164): data movement, bit-exact."""
+    from dsmnet_amd import costvolume as cv
+    from oracle import ops as OO
+    fL, fR = seeded(81, *shape), seeded(82, *shape)
+    got = cv.concat_volume_right(fL.cuda(), fR.cuda(), D)
+    assert torch.equal(got.cpu().contiguous(), OO.concat_volume_right(fL, fR, D))
+
+
+def test_gcnet_lr_left_output_equals_gcnet(hip_lib, golden_e2e):
+    """gcnet_LR(imL, imR)[0] is gcnet's output; its right output equals the left output of the
+    mirrored problem only up to the trunk's (non-symmetric) weights, so it is checked against the
+    oracle trunk on the oracle's right-referenced volume."""
+    from oracle import models as OM, ops as OO
+    from tests.golden.make_goldens import images
+    from tests.helpers import golden_state, maxerr
+    from dsmnet_amd.models.gcnet import gcnet_LR
+    sd, cfg = golden_state(golden_e2e, "gcnet")
+    imL, imR = images(cfg["image_seed"], *cfg["hw"])
+    m = gcnet_LR(192)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        oL, oR = m(imL.cuda(), imR.cuda())
+        n = OM.Net(sd)
+        fL, fR = OM.gcnet_features(n, imL), OM.gcnet_features(n, imR)
+        wantL = OO.soft_argmin(OM.gcnet_trunk(n, OO.concat_volume(fL, fR, 96, False)), None, negate=True).unsqueeze(1)
+        wantR = OO.soft_argmin(OM.gcnet_trunk(n, OO.concat_volume_right(fL, fR, 96)), None, negate=True).unsqueeze(1)
+    h, w = imL.shape[-2:]
+    assert maxerr(oL, wantL[:, :, :h, :w]) <= 1e-3
+    assert maxerr(oR, wantR[:, :, :h, :w]) <= 1e-3

@@ -139,3 +139,13 @@ def test_e2e_oracle_matches_golden(golden_e2e, name):
     else:
         for i, o in enumerate(out[1]):
             golden_e2e.compare("e2e.dispnetcorr.pr%d" % i, o, 1e-4)
+
+
+def test_right_referenced_volume_matches_golden():
+    """gcnet_LR's xR (models/gcnet.py:155-164): the oracle against the fixture written from the
+    reference's own lines (tests/golden/make_goldens.py --only lr)."""
+    from tests.conftest import Golden
+    g = Golden("lr")
+    for case in g.meta["volume_lr_cases"]:
+        fL, fR = seeded(case["seed"], *case["shape"]), seeded(case["seed"] + 100, *case["shape"])
+        g.compare(case["tag"] + ".xR", OO.concat_volume_right(fL, fR, case["D"]), 0.0)
