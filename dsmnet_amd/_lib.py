@@ -36,7 +36,8 @@ class Conv3dS3Args(ctypes.Structure):
                 ("Di", c_int), ("Hi", c_int), ("Wi", c_int),
                 ("Do", c_int), ("Ho", c_int), ("Wo", c_int),
                 ("Dr", c_int), ("Hr", c_int), ("Wr", c_int),
-                ("relu", c_int), ("grid", c_int), ("vol_virtual", c_int), ("vol_mask_left", c_int)]
+                ("relu", c_int), ("grid", c_int), ("vol_virtual", c_int), ("vol_mask_left", c_int),
+                ("tiling", c_int)]
 
 
 class Conv3dArgs(ctypes.Structure):
@@ -69,6 +70,7 @@ SIGNATURES = {
     "dsm_conv3d_fwd": (c_int, [ctypes.POINTER(Conv3dArgs), c_void_p]),
     "dsm_conv3d_plan": (c_int, [ctypes.POINTER(Conv3dArgs), ctypes.c_char_p, c_int]),
     "dsm_conv3d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
+    "dsm_conv2d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "dsm_conv3d_cout1_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "dsm_deconv3d_cout1_bwd": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "dsm_s3_bytes": (c_size_t, [c_int] * 5),
@@ -127,7 +129,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.dsm_abi_version() != 4:
+    if lib.dsm_abi_version() != 5:
         raise DsmnetHipError("libdsmnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -13,7 +13,16 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import costvolume as cv
+from . import blocks3d
 from .blocks3d import _versions
+
+# Training through the 2-D towers.  DSM_TRAIN_2D=fused (read by this host module) routes every tower
+# layer through costvolume.Conv2dFunction + the fused batch-statistics BN block; the default keeps the
+# stock torch layers: at PSMNet's training crop (256 x 512, maps of 64 x 128 pixels and smaller) the
+# fused path is correct (tests/test_conv2d_bwd_gpu.py) but SLOWER -- 38.0 vs 29.8 ms per replayed step
+# (DESIGN.md section 9): ~1,500 launches of 4-16 us each, tiles that fill a quarter of the CUs, and a
+# weight-gradient kernel that spends its time in atomics at these sizes.
+_FUSED_TRAIN_2D = __import__("os").environ.get("DSM_TRAIN_2D", "stock") == "fused"
 
 
 def s3in_ok(conv):
@@ -102,6 +111,43 @@ class _Folded2d(object):
         return self.packed, self.scale, self.shift
 
 
+def train_ok(conv, x):
+    """Can ``conv`` run on ``costvolume.Conv2dFunction`` (forward on the MFMA kernels, explicit
+    gradients) for the NCHW-shaped fp32 CUDA tensor ``x``?"""
+    if not (_FUSED_TRAIN_2D and isinstance(conv, nn.Conv2d) and torch.is_tensor(x) and x.is_cuda and
+            x.dtype == torch.float32 and conv.weight.dtype == torch.float32):
+        return False
+    k, s, d, p = conv.kernel_size, conv.stride, conv.dilation, conv.padding
+    if k[0] != k[1] or s[0] != s[1] or d[0] != d[1] or p[0] != p[1] or conv.groups != 1:
+        return False
+    if conv.bias is not None or conv.padding_mode != "zeros" or p[0] != d[0] * (k[0] // 2):
+        return False
+    return x.shape[1] == conv.in_channels and cv.conv2d_variant(conv.out_channels, s[0], k[0], d[0])
+
+
+def _run_conv2d_autograd(conv, bn, x, residual, relu):
+    """Training / autograd through a tower block: convolution with explicit gradients on the HIP
+    kernels, then batch-statistics BatchNorm + skip add + ReLU as one autograd node of two launches
+    each way (csrc/bn3d.hip on the (B, C, 1, H, W) view) -- instead of nn.Conv2d + nn.BatchNorm2d +
+    add + ReLU and their autograd nodes (models/psmnet/submodule.py:10-13,24-46)."""
+    y = cv.conv2d(x, conv.weight, conv.stride[0], conv.dilation[0])
+    if bn is not None and bn.training and blocks3d._FUSED_TRAIN_BN and y.shape[1] % 4 == 0 and y.shape[1] <= 256:
+        momentum = bn.momentum if bn.momentum is not None else 0.1
+        out = cv.bn_add_relu2d(y, bn.weight, bn.bias, residual,
+                               bn.running_mean if bn.track_running_stats else None,
+                               bn.running_var if bn.track_running_stats else None,
+                               1 if relu else 0, momentum, bn.eps)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        blocks3d.invalidate_folded_caches()   # running statistics changed through raw pointers
+        return out
+    if bn is not None:
+        y = bn(y)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
 def run_conv2d(folded, conv, bn, x, residual=None, relu=False, out="f32"):
     """conv (+BN) (+skip) (+ReLU): fused when possible, stock torch otherwise.  ``x``: a tensor or
     (eval) the map as an ``S3Volume``; ``out``: "f32" | "s3" | "both" (eval, bf16x3 layers)."""
@@ -116,6 +162,8 @@ def run_conv2d(folded, conv, bn, x, residual=None, relu=False, out="f32"):
                                k=conv.kernel_size[0], dilation=conv.dilation[0], out=out)
     if isinstance(x, cv.S3Volume) or out != "f32":
         raise RuntimeError("S3 activations exist on the fused eval path only")
+    if train_ok(conv, x):
+        return _run_conv2d_autograd(conv, bn, x, residual, relu)
     if x.shape[1] != conv.in_channels:            # zero-padded staging channels
         x = x[:, : conv.in_channels]
     y = conv(x)

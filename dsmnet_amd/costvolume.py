@@ -448,7 +448,7 @@ import os as _os
 # DSM_CONV_PRECISION=fp32|bf16x3 so that scripts and the parity tests can switch whole runs
 _OPTIONS = {"s3": True, "fuse_volume": True, "s3in": False,
             "conv_fp32": _os.environ.get("DSM_CONV_PRECISION", "").startswith("f"),
-            "conv_flags": 0}
+            "conv_flags": 0, "s3_tiling": 0}
 
 
 def set_option(name, value):
@@ -460,11 +460,13 @@ def set_option(name, value):
     take their input pre-split.  Off by default: measured in one process on the PSMNet forward
     (scripts/ab_paths.py, r02) it LOSES 4-17 % on every one of those kernels -- their operand
     split already rides in the shadow of the 32-cycle 32x32x16 MFMAs, while an S3 input costs 50 %
-    more staged bytes and its producer an epilogue split."""
+    more staged bytes and its producer an epilogue split.
+    ``s3_tiling`` -- dsm_conv3d_s3_args.tiling of every S3 convolution launch (0 = the library's
+    default, 1 = 8 x 32 tile / one workgroup per CU, 2 = 4 x 32 tile / two per CU)."""
     if name not in _OPTIONS:
         raise KeyError(name)
     old = _OPTIONS[name]
-    _OPTIONS[name] = int(value) if name == "conv_flags" else bool(value)
+    _OPTIONS[name] = int(value) if name in ("conv_flags", "s3_tiling") else bool(value)
     return old
 
 
@@ -606,6 +608,7 @@ def conv3d_s3_block(x, packed_weight, scale=None, shift=None, residual=None, rel
     a.Di, a.Hi, a.Wi = Di, Hi, Wi
     a.Do, a.Ho, a.Wo = Do, Ho, Wo
     a.relu, a.grid = int(relu), int(grid)
+    a.tiling = int(_OPTIONS["s3_tiling"])
     if x.features is not None:
         a.vol_virtual, a.vol_mask_left = 1, x.features[1]
     work = 54.0 * cin * 32 * B * Do * Ho * Wo
@@ -938,6 +941,98 @@ class BnAddRelu3dFunction(torch.autograd.Function):
 def bn_add_relu3d(y, gamma, beta, residual, running_mean, running_var, relu, momentum, eps):
     return BnAddRelu3dFunction.apply(y, gamma, beta, residual, running_mean, running_var, int(relu),
                                      float(momentum), float(eps))
+
+
+# ----------------------------------------------------------------------------
+# the 2-D towers in training: convolution with explicit gradients, batch-statistics BN
+# ----------------------------------------------------------------------------
+# (stride, Cout/32, k, dilation) variants of the 2-D MFMA convolution compiled in csrc/conv3d.hip
+_CONV2D_VARIANTS = {(1, 1, 3, 1), (1, 2, 3, 1), (1, 4, 3, 1), (1, 4, 3, 2), (2, 1, 3, 1),
+                    (2, 2, 3, 1), (1, 1, 1, 1), (1, 4, 1, 1), (2, 2, 1, 1)}
+
+
+def conv2d_variant(cout, stride, k, dilation):
+    return cout in (32, 64, 128) and (stride, cout // 32, k, dilation) in _CONV2D_VARIANTS
+
+
+def _wgrad2d(x_cl, g_cl, stride, dilation):
+    """dW[g][c][ky][kx] = sum_v X[v*stride + (k - 1)*dilation][c] G[v][g]  ->  (cg, cx, 3, 3)."""
+    B, cx, Hx, Wx = x_cl.shape
+    _, cg, Hg, Wg = g_cl.shape
+    ws = torch.empty((cx // 32) * (cg // 32) * 9 * 1024, device=x_cl.device, dtype=torch.float32)
+    dw = torch.empty((cg, cx, 3, 3), device=x_cl.device, dtype=torch.float32)
+    with torch.cuda.device(x_cl.device), _timed("conv2d_wgrad_kernel", 18.0 * cx * cg * B * Hg * Wg):
+        rc = _lib.load().dsm_conv2d_wgrad(_p(x_cl), _p(g_cl), _p(ws), _p(dw), B, cx, cg, Hx, Wx,
+                                          Hg, Wg, int(stride), int(dilation), _stream())
+    _lib.check(rc, "dsm_conv2d_wgrad")
+    return dw
+
+
+class Conv2dFunction(torch.autograd.Function):
+    """y = conv2d(x, weight), k in {1, 3}, padding = dilation * (k // 2), no bias: the ``nn.Conv2d`` of
+    ``convbn`` (models/psmnet/submodule.py:10-13) with the forward, bwd-data (a convolution again,
+    flipped transposed weights) and bwd-weight (``dsm_conv2d_wgrad``; 1x1: one GEMM) on the gfx950
+    kernels, NHWC.  Gradients no kernel here covers (stride-2 bwd-data, the 3-channel image layer's
+    bwd-weight, channel counts outside the compiled variants) come from
+    ``aten.convolution_backward`` on the same tensors.  In the reference this is autograd through
+    nn.Conv2d."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, dilation):
+        _require_device("Conv2dFunction", x, weight)
+        cout, cin, k, _ = weight.shape
+        x = x.contiguous(memory_format=_CL2D)
+        xs = x
+        if cin % 16:                                   # the image: 3 -> 16 staged channels
+            xs = torch.zeros((x.shape[0], (cin + 15) // 16 * 16) + tuple(x.shape[2:]), device=x.device,
+                             dtype=x.dtype).contiguous(memory_format=_CL2D)
+            xs[:, :cin] = x
+        packed = pack_conv2d_weight(weight, xs.shape[1])
+        y = conv2d_block(xs, packed, cout, stride=stride, k=k, dilation=dilation)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (int(stride), int(dilation))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, dil = ctx.cfg
+        cout, cin, k, _ = weight.shape
+        gy = gy.contiguous(memory_format=_CL2D)
+        w = weight.detach()
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = dw = None
+        if need_dx and stride == 1 and conv2d_variant(cin, 1, k, dil) and cout % 16 == 0:
+            wt = (w.flip(2, 3) if k == 3 else w).transpose(0, 1).contiguous()
+            dx = conv2d_block(gy, pack_conv2d_weight(wt), cin, stride=1, k=k, dilation=dil)
+        if need_dw and k == 3 and cin % 32 == 0 and cout % 32 == 0:
+            dw = _wgrad2d(x, gy, stride, dil)
+        elif need_dw and k == 1:
+            xg = x if stride == 1 else x[:, :, ::stride, ::stride]
+            dw = torch.matmul(gy.permute(0, 2, 3, 1).reshape(-1, cout).t(),
+                              xg.permute(0, 2, 3, 1).reshape(-1, cin)).view(cout, cin, 1, 1)
+        mask = [need_dx and dx is None, need_dw and dw is None, False]
+        if mask[0] or mask[1]:
+            pad = dil * (k // 2)
+            rdx, rdw, _ = torch.ops.aten.convolution_backward(
+                gy, x, w, None, [stride, stride], [pad, pad], [dil, dil], False, [0, 0], 1, mask)
+            dx = rdx if mask[0] else dx
+            dw = rdw if mask[1] else dw
+        return dx, dw, None, None
+
+
+def conv2d(x, weight, stride=1, dilation=1):
+    return Conv2dFunction.apply(x, weight, int(stride), int(dilation))
+
+
+def bn_add_relu2d(y, gamma, beta, residual, running_mean, running_var, relu, momentum, eps):
+    """Train-mode BatchNorm2d (+ skip add) (+ ReLU) on NHWC maps: the 3-D kernels on (B, C, 1, H, W)
+    views of the same memory."""
+    y = y.contiguous(memory_format=_CL2D).unsqueeze(2)
+    if residual is not None:
+        residual = residual.contiguous(memory_format=_CL2D).unsqueeze(2)
+    return bn_add_relu3d(y, gamma, beta, residual, running_mean, running_var, relu, momentum,
+                         eps).squeeze(2)
 
 
 # ----------------------------------------------------------------------------

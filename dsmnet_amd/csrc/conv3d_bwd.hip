@@ -39,9 +39,15 @@ struct WgradParams {
 };
 
 // S: stride of X relative to G.  Tile: 1 z x TY rows x 32 columns of G voxels.
-template <int S, int TY>
+// KZ = 3: the 27-tap 3-D layers, wave w owns taps {w, w + 4, ...}.  KZ = 1: the 9-tap 2-D layers
+// (maps as D = 1 volumes; DIL = tap spacing), every wave owns all nine taps and a quarter of the
+// tile's voxels instead (9 taps do not divide over 4 waves).
+template <int S, int TY, int KZ = 3, int DIL = 1>
 __global__ __launch_bounds__(NT_, 1) void conv3d_wgrad_kernel(WgradParams p) {
-  constexpr int IY = (TY - 1) * S + 3, IX = 31 * S + 3, IZ = 3;
+  constexpr int IY = (TY - 1) * S + 2 * DIL + 1, IX = 31 * S + 2 * DIL + 1, IZ = KZ;
+  constexpr int NTAP = 9 * KZ, NACC = KZ == 3 ? 7 : 9;
+  static_assert(KZ == 3 || KZ == 1, "3-D (27 taps) or 2-D (9 taps)");
+  static_assert(KZ == 1 || DIL == 1, "dilation: 2-D layers only");
   constexpr int NXE = IZ * IY * IX * 8;            // X tile: 32 channels = 8 x 16 B per voxel
   constexpr int NGE = TY * 32 * 8;                 // G tile
   constexpr int NPX = (NXE + NT_ - 1) / NT_, NPG = (NGE + NT_ - 1) / NT_;
@@ -54,9 +60,9 @@ __global__ __launch_bounds__(NT_, 1) void conv3d_wgrad_kernel(WgradParams p) {
   const int r = lane & 31, h = lane >> 5;
   const int pair = blockIdx.y;
   const int ct = pair / (p.Cg / 32), gtile = pair % (p.Cg / 32);   // X-channel tile, G-channel tile
-  f32x16 acc[7];
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int a = 0; a < 7; ++a)
+  for (int a = 0; a < NACC; ++a)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
 
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(NT_, 1) void conv3d_wgrad_kernel(WgradParams p) {
       if (e < NXE) {
         const int q = e & 7, v = e >> 3;
         const int xx = v % IX, yy = (v / IX) % IY, zz = v / (IX * IY);
-        const int zi = tz * S - 1 + zz, yi = ty0 * S - 1 + yy, xi = tx0 * S - 1 + xx;
+        const int zi = tz * S - KZ / 2 + zz, yi = ty0 * S - DIL + yy, xi = tx0 * S - DIL + xx;
         f32x4 val = {0.f, 0.f, 0.f, 0.f};
         if (zi >= 0 && zi < p.Dx && yi >= 0 && yi < p.Hx && xi >= 0 && xi < p.Wx)
           val = *reinterpret_cast<const f32x4*>(
@@ -95,14 +101,15 @@ __global__ __launch_bounds__(NT_, 1) void conv3d_wgrad_kernel(WgradParams p) {
     }
     __syncthreads();
     // wave w: taps w, w+4, ...; per tap K = TY*32 voxels, two per MFMA (k = h)
-    sfor<0, 7>([&](auto ac) {
+    sfor<0, NACC>([&](auto ac) {
       constexpr int a = decltype(ac)::value;
-      const int tap = wave + 4 * a;
-      if (tap < 27) {
+      const int tap = KZ == 3 ? wave + 4 * a : a;
+      if (tap < NTAP) {
         const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-        const float* xa = xf + ((dz * IY + dy) * IX + dx) * 32 + r;       // + voxel*32*S...
+        const float* xa = xf + ((dz * IY + dy * DIL) * IX + dx * DIL) * 32 + r;   // + voxel*32*S...
+        const int k0 = KZ == 3 ? 0 : wave * (TY * 4), k1 = KZ == 3 ? TY * 16 : k0 + TY * 4;
 #pragma unroll 4
-        for (int kk = 0; kk < TY * 16; ++kk) {
+        for (int kk = k0; kk < k1; ++kk) {
           const int vy = kk >> 4, vx = ((kk & 15) << 1) + h;              // voxel of this lane's k
           const float av = xa[((vy * S) * IX + vx * S) * 32];
           const float bv = gf[(vy * 32 + vx) * 32 + r];
@@ -112,11 +119,11 @@ __global__ __launch_bounds__(NT_, 1) void conv3d_wgrad_kernel(WgradParams p) {
     });
   }
   // flush: ws[pair][tap][c][g] += acc  (row = c, column = g on the lanes)
-  sfor<0, 7>([&](auto ac) {
+  sfor<0, NACC>([&](auto ac) {
     constexpr int a = decltype(ac)::value;
-    const int tap = wave + 4 * a;
-    if (tap < 27) {
-      float* dst = p.ws + (((long)pair * 27 + tap) * 32) * 32 + r;
+    const int tap = KZ == 3 ? wave + 4 * a : a;
+    if (tap < NTAP) {
+      float* dst = p.ws + (((long)pair * NTAP + tap) * 32) * 32 + r;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int c = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -126,17 +133,45 @@ __global__ __launch_bounds__(NT_, 1) void conv3d_wgrad_kernel(WgradParams p) {
   });
 }
 
-// ws [pair = ct*(Cg/32)+gt][tap][c][g]  ->  dW[g_abs][c_abs][tap]   (torch (G, C, 3,3,3))
+// ws [pair = ct*(Cg/32)+gt][tap][c][g]  ->  dW[g_abs][c_abs][tap]   (torch (G, C, 3,3,3) / (G, C, 3,3))
 __global__ void wgrad_permute_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cx,
-                                     int Cg) {
-  const long n = (long)Cx * Cg * 27;
+                                     int Cg, int ntap) {
+  const long n = (long)Cx * Cg * ntap;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int tap = i % 27;
-  const int c = (i / 27) % Cx;
-  const int g = i / (27L * Cx);
+  const int tap = i % ntap;
+  const int c = (i / ntap) % Cx;
+  const int g = i / ((long)ntap * Cx);
   const int pair = (c / 32) * (Cg / 32) + g / 32;
-  dw[i] = ws[(((long)pair * 27 + tap) * 32 + (c & 31)) * 32 + (g & 31)];
+  dw[i] = ws[(((long)pair * ntap + tap) * 32 + (c & 31)) * 32 + (g & 31)];
+}
+
+template <int S, int TY, int KZ, int DIL>
+int launch_wgrad(WgradParams p, float* dw, hipStream_t s) {
+  constexpr int IY = (TY - 1) * S + 2 * DIL + 1, IX = 31 * S + 2 * DIL + 1;
+  constexpr int NTAP = 9 * KZ;
+  constexpr size_t lds = (size_t)(KZ * IY * IX * 8 + TY * 32 * 8) * 16;
+  static_assert(lds <= 160 * 1024, "LDS");
+  const size_t wsbytes = (size_t)p.npair * NTAP * 32 * 32 * sizeof(float);
+  if (hipMemsetAsync(p.ws, 0, wsbytes, s) != hipSuccess) return DSM_ERR_LAUNCH;
+  p.ntx = dsm_cdiv(p.Wg, 32); p.nty = dsm_cdiv(p.Hg, TY);
+  const long nt = (long)p.B * p.Dg * p.nty * p.ntx;
+  DSM_REQUIRE(nt < (1L << 30), DSM_ERR_UNSUPPORTED);
+  p.ntiles = (int)nt;
+  int bx = 256 / p.npair; if (bx < 1) bx = 1;
+  if (bx > p.ntiles) bx = p.ntiles;
+  static thread_local bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<S, TY, KZ, DIL>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return DSM_ERR_LAUNCH;
+    configured = true;
+  }
+  hipLaunchKernelGGL((conv3d_wgrad_kernel<S, TY, KZ, DIL>), dim3(bx, p.npair), dim3(NT_), lds, s, p);
+  const long n = (long)p.Cx * p.Cg * NTAP;
+  hipLaunchKernelGGL(wgrad_permute_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s,
+                     (const float*)p.ws, dw, p.Cx, p.Cg, NTAP);
+  return dsm_launch_status();
 }
 
 // ---- Cout = 1 (classifier heads): y[v] = sum_tap sum_c x[v+tap-1][c] w[tap][c] ------------
@@ -185,6 +220,84 @@ __global__ __launch_bounds__(256) void cout1_bwd_weight_kernel(const float* __re
   }
 }
 
+
+// The same sums with x read ONCE: a thread owns a channel quad q and a voxel slot, keeps all 27
+// taps' partial sums (27 x f32x4) in registers across the tiles of its workgroup, and pairs each x
+// value with the 27 neighbouring g values from a small LDS tile (broadcast reads).  NQ = C / 4 quads
+// x (256 / NQ) voxels per tile; a few fat workgroups so that the final atomics stay few (27 C per
+// workgroup after the in-wave and cross-wave reductions).  The kernel above re-reads x 27 times
+// through L2 and issues 27 C atomics per ROW (0.36 ms per head at 48 x 64 x 128).
+template <int NQ>
+__global__ __launch_bounds__(256) void cout1_bwd_weight_tile_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ g,
+                                                                    float* __restrict__ dw, int B,
+                                                                    int D, int H, int W) {
+  constexpr int VT = 256 / NQ;                     // voxels (along x) per tile
+  constexpr int C = 4 * NQ;
+  __shared__ float gl[9 * (VT + 2)];
+  __shared__ float red[3 * 27 * C];                // waves 1..3's sums
+  const int q = threadIdx.x % NQ, vs = threadIdx.x / NQ;
+  const int nxc = (W + VT - 1) / VT;
+  const long ntile = (long)B * D * H * nxc;
+  f32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_x = [&](long t) {                      // this thread's x value of tile t (zeros outside)
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t < ntile) {
+      const int xu = (int)(t % nxc) * VT + vs;
+      if (xu < W) v = *reinterpret_cast<const f32x4*>(x + ((t / nxc) * W + xu) * C + 4 * q);
+    }
+    return v;
+  };
+  f32x4 xnext = load_x(blockIdx.x);
+  for (long t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const int xc = t % nxc; long r = t / nxc;
+    const int y = r % H; r /= H;
+    const int z = r % D; const int b = r / D;
+    const int x0 = xc * VT;
+    const f32x4 xv = xnext;
+    xnext = load_x(t + gridDim.x);                 // in flight across this tile's work
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * (VT + 2); i += 256) {
+      const int xx = x0 - 1 + i % (VT + 2), ry = (i / (VT + 2)) % 3, rz = i / (3 * (VT + 2));
+      const int yy = y - 1 + ry, zz = z - 1 + rz;
+      gl[i] = (xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D)
+                  ? g[(((long)b * D + zz) * H + yy) * W + xx] : 0.f;
+    }
+    __syncthreads();
+    // x[u] meets g[u - tap + 1]: rows (2 - dz, 2 - dy), column vs + 2 - dx of the tile
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      acc[tap] += xv * gl[((2 - dz) * 3 + (2 - dy)) * (VT + 2) + vs + 2 - dx];
+    }
+  }
+  // voxel slots of one wave: lanes q + NQ * k
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+    for (int off = NQ; off < 64; off <<= 1) {
+      acc[tap].x += __shfl_xor(acc[tap].x, off); acc[tap].y += __shfl_xor(acc[tap].y, off);
+      acc[tap].z += __shfl_xor(acc[tap].z, off); acc[tap].w += __shfl_xor(acc[tap].w, off);
+    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (NQ <= 64 && wave > 0 && lane < NQ)
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap)
+      *reinterpret_cast<f32x4*>(red + ((wave - 1) * 27 + tap) * C + 4 * lane) = acc[tap];
+  __syncthreads();
+  if (wave == 0 && lane < NQ)
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      f32x4 a = acc[tap];
+#pragma unroll
+      for (int w = 0; w < 3; ++w) a += *reinterpret_cast<const f32x4*>(red + (w * 27 + tap) * C + 4 * lane);
+      float* o = dw + tap * C + 4 * lane;
+      atomicAdd(o, a.x); atomicAdd(o + 1, a.y); atomicAdd(o + 2, a.z); atomicAdd(o + 3, a.w);
+    }
+}
 
 // ----------------------------------------------------------------------------
 // ConvTranspose3d(C -> 1, k3, s2, p1, op1) backward -- GCNet's head l37 (models/gcnet.py:63,98).
@@ -272,34 +385,30 @@ extern "C" int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw
   p.x = (const float*)x; p.g = (const float*)g; p.ws = (float*)ws;
   p.B = B; p.Cx = Cx; p.Cg = Cg; p.Dx = Dx; p.Hx = Hx; p.Wx = Wx; p.Dg = Dg; p.Hg = Hg; p.Wg = Wg;
   p.npair = (Cx / 32) * (Cg / 32);
-  const size_t wsbytes = (size_t)p.npair * 27 * 32 * 32 * sizeof(float);
-  if (hipMemsetAsync(ws, 0, wsbytes, s) != hipSuccess) return DSM_ERR_LAUNCH;
-  constexpr int TY1 = 4, TY2 = 2;
-  const int TY = stride == 1 ? TY1 : TY2;
-  p.ntx = dsm_cdiv(Wg, 32); p.nty = dsm_cdiv(Hg, TY);
-  const long nt = (long)B * Dg * p.nty * p.ntx;
-  DSM_REQUIRE(nt < (1L << 30), DSM_ERR_UNSUPPORTED);
-  p.ntiles = (int)nt;
-  int bx = 256 / p.npair; if (bx < 1) bx = 1;
-  if (bx > p.ntiles) bx = p.ntiles;
-  dim3 grid(bx, p.npair);
-  if (stride == 1) {
-    const size_t lds = (size_t)(3 * (TY1 + 2) * 34 * 8 + TY1 * 32 * 8) * 16;
-    if (hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<1, TY1>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return DSM_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv3d_wgrad_kernel<1, TY1>), grid, dim3(NT_), lds, s, p);
-  } else {
-    const size_t lds = (size_t)(3 * ((TY2 - 1) * 2 + 3) * 65 * 8 + TY2 * 32 * 8) * 16;
-    if (hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<2, TY2>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return DSM_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv3d_wgrad_kernel<2, TY2>), grid, dim3(NT_), lds, s, p);
-  }
-  const long n = (long)Cx * Cg * 27;
-  hipLaunchKernelGGL(wgrad_permute_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s,
-                     (const float*)ws, (float*)dw, Cx, Cg);
-  return dsm_launch_status();
+  if (stride == 1) return launch_wgrad<1, 4, 3, 1>(p, (float*)dw, s);
+  return launch_wgrad<2, 2, 3, 1>(p, (float*)dw, s);
+}
+
+// The same for the 2-D towers' 3x3 layers (padding = dilation): x: (B,Hx,Wx,Cx) NHWC,
+// g: (B,Hg,Wg,Cg); ws: (Cx/32)*(Cg/32)*9*32*32 floats; dw: (Cg, Cx, 3, 3), overwritten.
+extern "C" int dsm_conv2d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, int Cx,
+                                int Cg, int Hx, int Wx, int Hg, int Wg, int stride, int dilation,
+                                dsm_stream_t stream) {
+  DSM_REQUIRE(x && g && ws && dw, DSM_ERR_ARG);
+  DSM_REQUIRE(B > 0 && Cx > 0 && Cg > 0 && Hx > 0 && Wx > 0 && Hg > 0 && Wg > 0, DSM_ERR_ARG);
+  DSM_REQUIRE((stride == 1 && (dilation == 1 || dilation == 2)) || (stride == 2 && dilation == 1),
+              DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(Cx % 32 == 0 && Cg % 32 == 0, DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(dsm_aligned16(x) && dsm_aligned16(g), DSM_ERR_ALIGN);
+  hipStream_t s = (hipStream_t)stream;
+  dsm_clear_stale_error();
+  WgradParams p;
+  p.x = (const float*)x; p.g = (const float*)g; p.ws = (float*)ws;
+  p.B = B; p.Cx = Cx; p.Cg = Cg; p.Dx = 1; p.Hx = Hx; p.Wx = Wx; p.Dg = 1; p.Hg = Hg; p.Wg = Wg;
+  p.npair = (Cx / 32) * (Cg / 32);
+  if (stride == 2) return launch_wgrad<2, 4, 1, 1>(p, (float*)dw, s);
+  if (dilation == 2) return launch_wgrad<1, 8, 1, 2>(p, (float*)dw, s);
+  return launch_wgrad<1, 8, 1, 1>(p, (float*)dw, s);
 }
 
 // Cout = 1 convolution (stride 1): g: (B,D,H,W); x: (B,D,H,W,C); w_packed: [27][C] (as packed
@@ -322,8 +431,17 @@ extern "C" int dsm_conv3d_cout1_bwd(const void* x, const void* g, const void* w_
     DSM_REQUIRE(x, DSM_ERR_ARG);
     if (hipMemsetAsync(dw_tapmajor, 0, (size_t)27 * C * sizeof(float), s) != hipSuccess)
       return DSM_ERR_LAUNCH;
-    hipLaunchKernelGGL(cout1_bwd_weight_kernel, dim3(B * D * H), dim3(256), 0, s, (const float*)x,
-                       (const float*)g, (float*)dw_tapmajor, B, C, D, H, W);
+    const long ntile32 = (long)B * D * H * dsm_cdiv(W, 32);
+    const int blocks = (int)(ntile32 < 768 ? ntile32 : 768);   // three resident per CU
+    if (C == 32 && dsm_aligned16(x))
+      hipLaunchKernelGGL(cout1_bwd_weight_tile_kernel<8>, dim3(blocks), dim3(256), 0, s, (const float*)x,
+                         (const float*)g, (float*)dw_tapmajor, B, D, H, W);
+    else if (C == 64 && dsm_aligned16(x))
+      hipLaunchKernelGGL(cout1_bwd_weight_tile_kernel<16>, dim3(blocks), dim3(256), 0, s, (const float*)x,
+                         (const float*)g, (float*)dw_tapmajor, B, D, H, W);
+    else
+      hipLaunchKernelGGL(cout1_bwd_weight_kernel, dim3(B * D * H), dim3(256), 0, s, (const float*)x,
+                         (const float*)g, (float*)dw_tapmajor, B, C, D, H, W);
   }
   return dsm_launch_status();
 }

@@ -47,6 +47,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -75,6 +76,19 @@ __device__ __forceinline__ void split_unit(const f32x4 lo4, const f32x4 hi4, u32
       if (k < 2) { r[2 * i] -= bf16_lo(u[i]); r[2 * i + 1] -= bf16_hi(u[i]); }
     }
     pl[k] = u32x4{u[0], u[1], u[2], u[3]};
+  }
+}
+__device__ __forceinline__ void split_half(const f32x4 v4, u32x2 (&pl)[3]) {   // 4 of a unit's 8 elements
+  float r[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    unsigned u[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u[i] = pack_bf16(r[2 * i], r[2 * i + 1]);
+      if (k < 2) { r[2 * i] -= bf16_lo(u[i]); r[2 * i + 1] -= bf16_hi(u[i]); }
+    }
+    pl[k] = u32x2{u[0], u[1]};
   }
 }
 __device__ __forceinline__ void join_unit(const u32x4 (&pl)[3], f32x4& lo4, f32x4& hi4) {
@@ -252,23 +266,45 @@ struct S3ConvParams {
   unsigned wbytes;
 };
 
-constexpr int S3_TY = 8, S3_IY = 10, S3_IX = 34;
-constexpr int S3_NV = S3_IY * S3_IX;              // 340 voxels of the halo box
-constexpr int S3_NVP = 352;                       // padded to a multiple of 16: (plane, g) rows 256-B aligned
-constexpr int S3_ROW = S3_NVP * 16;               // 5,632 B
-constexpr int S3_IMG = 12 * S3_ROW;               // 67,584 B = 66 pieces of 1 KiB
-static_assert(S3_IMG % 1024 == 0, "the image is 66 whole 1-KiB pieces");
-constexpr int S3_IMGP = 68 * 1024;                // image stride: two spare pieces take waves 2, 3's 17th store
-constexpr int S3_NPW = 17;                        // pieces per wave (waves 2, 3: the 17th is the spare)
+// Two tilings of the same kernel (dsm_conv3d_s3_args.tiling; S3_DEFAULT_TILING when that is 0):
+//   V = 0: 8 x 32 tile, one workgroup per CU, wave = (row half, x half), both 16-channel A blocks;
+//   V = 1: 4 x 32 tile, two workgroups per CU (<= 256 registers), wave = (cout half, x half).
+#ifndef S3_DEFAULT_TILING
+#define S3_DEFAULT_TILING 1   // 8 x 32: the whole-forward A/B (profiles/r02_ablation.md section 4)
+#endif
+constexpr int S3_IX = 34;
 constexpr int S3_NSTEP = 27;
 constexpr int S3_WSTEP = 6 * 1024;                // weight bytes per (tap position, z-tap) step
-constexpr int S3_LDS = 2 * S3_IMGP + 256;
+template <int V> struct S3Cfg {
+  static constexpr int TY = V == 0 ? 8 : 4, IY = TY + 2;
+  static constexpr int NV = IY * S3_IX;                      // voxels of the halo box: 340 | 204
+  static constexpr int NVP = (NV + 15) / 16 * 16;            // (plane, g) rows 256-B aligned: 352 | 208
+  static constexpr int ROW = NVP * 16;                       // 5,632 | 3,328 B
+  static constexpr int IMG = 12 * ROW;                       // 67,584 B = 66 pieces | 39,936 B = 39 pieces
+  static constexpr int NPIECE = IMG / 1024;
+  static constexpr int NPW = (NPIECE + 3) / 4;               // pieces per wave: 17 | 10
+  // V = 0: the image stride leaves two spare pieces for waves 2, 3's 17th store; V = 1 has no room
+  // (two workgroups share the CU's 160 KiB) and predicates the last piece instead.
+  static constexpr bool SPARE = V == 0;
+  static constexpr int IMGP = SPARE ? 4 * NPW * 1024 : IMG;
+  static constexpr int LDS = 2 * IMGP + 256;
+  static constexpr int NA = V == 0 ? 2 : 1;                  // 16-channel A blocks per wave
+  static constexpr int WGS = V == 0 ? 1 : 2;                 // workgroups per CU
+  static_assert(IMG % 1024 == 0, "whole 1-KiB pieces");
+  static_assert(NPW <= S3_NSTEP - 3 + 4, "staging schedule");
+};
 
-__global__ __launch_bounds__(256, 1) void conv_s3_kernel(S3ConvParams p) {
+template <int V>
+__global__ __launch_bounds__(256, S3Cfg<V>::WGS) void conv_s3_kernel(S3ConvParams p) {
+  using C = S3Cfg<V>;
+  constexpr int S3_TY = C::TY, S3_NV = C::NV, S3_NVP = C::NVP, S3_ROW = C::ROW, S3_IMGP = C::IMGP,
+                S3_NPW = C::NPW, NA = C::NA;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int rh = wave >> 1, xh = wave & 1;
+  const int hi = wave >> 1, xh = wave & 1;
+  const int row0 = V == 0 ? 4 * hi : 0;       // V = 0: the wave's 4 rows of the 8-row tile
+  const int a0 = V == 0 ? 0 : hi;             // V = 1: the wave's 16-channel block
   const int ncg = p.Cin >> 5;
 
   // this workgroup's range of the linearised (column, output plane) space; workgroups on one XCD
@@ -282,11 +318,11 @@ __global__ __launch_bounds__(256, 1) void conv_s3_kernel(S3ConvParams p) {
   float* const aff = reinterpret_cast<float*>(lds_raw + 2 * S3_IMGP);
   if (tid < 64) aff[tid] = tid < 32 ? (p.scale ? p.scale[tid] : 1.f) : (p.shift ? p.shift[tid - 32] : 0.f);
   __syncthreads();
-  f32x4 sc[2], sh[2];
+  f32x4 sc[NA], sh[NA];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    sc[a] = *reinterpret_cast<const f32x4*>(aff + 16 * a + 4 * g);
-    sh[a] = *reinterpret_cast<const f32x4*>(aff + 32 + 16 * a + 4 * g);
+  for (int a = 0; a < NA; ++a) {
+    sc[a] = *reinterpret_cast<const f32x4*>(aff + 16 * (a0 + a) + 4 * g);
+    sh[a] = *reinterpret_cast<const f32x4*>(aff + 32 + 16 * (a0 + a) + 4 * g);
   }
 
   // ---- chunk iterator: live (input plane, channel group) pairs of the segments of [u_begin, u_end)
@@ -346,12 +382,16 @@ __global__ __launch_bounds__(256, 1) void conv_s3_kernel(S3ConvParams p) {
   const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.wbytes);
   const unsigned lane16 = lane * 16u;
   const int st_off = wave * 1024 + lane * 16;                  // + 4096 t: the slot of piece wave + 4 t
-  // activation fragment of this lane: voxel (4 rh + r + ky, 16 xh + j + kx), unit g, plane pl
-  const int rd_off = g * S3_ROW + ((4 * rh) * S3_IX + 16 * xh + j) * 16;
+  auto piece_ok = [&](int t) { return C::SPARE || wave + 4 * t < C::NPIECE; };
+  // activation fragment of this lane: voxel (row0 + r + ky, 16 xh + j + kx), unit g, plane pl
+  const int rd_off = g * S3_ROW + (row0 * S3_IX + 16 * xh + j) * 16;
 
-  f32x4 acc[3][4][2];
-  bf16x8 xq[2][4][3];           // [tap-position parity][row][plane]
-  bf16x8 wq[3][2][3];           // [step % 3][a][plane]
+  f32x4 acc[3][4][NA];
+  // [tap-position parity][row][plane]; V = 1 has one set: a row's fragment of the next tap position
+  // takes the registers of the row just finished in the tap position's last step
+  constexpr int XQ = V == 0 ? 2 : 1;
+  bf16x8 xq[XQ][4][3];
+  bf16x8 wq[3][NA][3];          // [step % 3][a][plane]
   f32x4 stg[4];
 
   auto zero_set = [&](auto sc_) {
@@ -359,23 +399,23 @@ __global__ __launch_bounds__(256, 1) void conv_s3_kernel(S3ConvParams p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int a = 0; a < 2; ++a) acc[s][r][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int a = 0; a < NA; ++a) acc[s][r][a] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto wload = [&](auto sc_, unsigned wb) {                     // weights of step s (of the chunk at wb)
     constexpr int s = decltype(sc_)::value;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
       for (int q = 0; q < 3; ++q)
         wq[s % 3][a][q] = __builtin_bit_cast(
-            bf16x8, buffer_load16(wrsrc, lane16, wb + s * S3_WSTEP + (a * 3 + q) * 1024));
+            bf16x8, buffer_load16(wrsrc, lane16 + (unsigned)a0 * 3072u, wb + s * S3_WSTEP + (a * 3 + q) * 1024));
   };
   auto xload = [&](auto tpc, auto rc, const unsigned char* rd) {
     constexpr int tp = decltype(tpc)::value, r = decltype(rc)::value;
     constexpr int ky = tp / 3, kx = tp % 3;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
-      xq[tp & 1][r][q] = *reinterpret_cast<const bf16x8*>(rd + q * 4 * S3_ROW + ((r + ky) * S3_IX + kx) * 16);
+      xq[tp & (XQ - 1)][r][q] = *reinterpret_cast<const bf16x8*>(rd + q * 4 * S3_ROW + ((r + ky) * S3_IX + kx) * 16);
   };
 
   // epilogue of accumulator set 0 = output plane zo of the column
@@ -385,35 +425,42 @@ __global__ __launch_bounds__(256, 1) void conv_s3_kernel(S3ConvParams p) {
     if (xo >= p.Wo) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int yo = ty * S3_TY + 4 * rh + r;
+      const int yo = ty * S3_TY + row0 + r;
       if (yo >= p.Ho) continue;
-      f32x4 v[2];
+      f32x4 v[NA];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
+      for (int a = 0; a < NA; ++a) {
         v[a] = acc[0][r][a] * sc[a] + sh[a];
         if (p.relu == 2) { v[a].x = fmaxf(v[a].x, 0.f); v[a].y = fmaxf(v[a].y, 0.f); v[a].z = fmaxf(v[a].z, 0.f); v[a].w = fmaxf(v[a].w, 0.f); }
       }
       if (p.res) {
-        const float* rv = p.res + ((((long)b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo) * 32 + 4 * g;
-        v[0] += *reinterpret_cast<const f32x4*>(rv);
-        v[1] += *reinterpret_cast<const f32x4*>(rv + 16);
+        const float* rv = p.res + ((((long)b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo) * 32 + 16 * a0 + 4 * g;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) v[a] += *reinterpret_cast<const f32x4*>(rv + 16 * a);
       }
       if (p.relu == 1) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) { v[a].x = fmaxf(v[a].x, 0.f); v[a].y = fmaxf(v[a].y, 0.f); v[a].z = fmaxf(v[a].z, 0.f); v[a].w = fmaxf(v[a].w, 0.f); }
+        for (int a = 0; a < NA; ++a) { v[a].x = fmaxf(v[a].x, 0.f); v[a].y = fmaxf(v[a].y, 0.f); v[a].z = fmaxf(v[a].z, 0.f); v[a].w = fmaxf(v[a].w, 0.f); }
       }
       const long vox = (((long)b * p.Do + zo) * p.Ho + yo) * p.Wo + xo;
       if (p.y) {
-        float* yv = p.y + vox * 32 + 4 * g;
-        *reinterpret_cast<f32x4*>(yv) = v[0];
-        *reinterpret_cast<f32x4*>(yv + 16) = v[1];
+        float* yv = p.y + vox * 32 + 16 * a0 + 4 * g;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) *reinterpret_cast<f32x4*>(yv + 16 * a) = v[a];
       }
       if (p.ys3) {
-        u32x4 pl[3];
-        split_unit(v[0], v[1], pl);
         unsigned char* o = p.ys3 + ((((((long)b * p.Do + zo) * p.Ho + yo) * 12) + g) * p.Wo + xo) * 16;
+        if constexpr (NA == 2) {
+          u32x4 pl[3];
+          split_unit(v[0], v[1], pl);
 #pragma unroll
-        for (int q2 = 0; q2 < 3; ++q2) *reinterpret_cast<u32x4*>(o + (long)q2 * 4 * p.Wo * 16) = pl[q2];
+          for (int q2 = 0; q2 < 3; ++q2) *reinterpret_cast<u32x4*>(o + (long)q2 * 4 * p.Wo * 16) = pl[q2];
+        } else {                        // this wave's half of the unit: elements 4 a0 .. 4 a0 + 3
+          u32x2 pl[3];
+          split_half(v[0], pl);
+#pragma unroll
+          for (int q2 = 0; q2 < 3; ++q2) *reinterpret_cast<u32x2*>(o + (long)q2 * 4 * p.Wo * 16 + 8 * a0) = pl[q2];
+        }
       }
     }
   };
@@ -426,8 +473,9 @@ __global__ __launch_bounds__(256, 1) void conv_s3_kernel(S3ConvParams p) {
     const int xmin0 = chunk_xmin(cur);
 #pragma unroll
     for (int t = 0; t < S3_NPW; ++t)
-      *reinterpret_cast<f32x4*>(lds_raw + st_off + 4096 * t) =
-          buffer_load16(rs0, vx[t] >= xmin0 ? voff[t] : OOBV, 0);
+      if (piece_ok(t))
+        *reinterpret_cast<f32x4*>(lds_raw + st_off + 4096 * t) =
+            buffer_load16(rs0, vx[t] >= xmin0 ? voff[t] : OOBV, 0);
   }
   static_for<0, 3>([&](auto s) { zero_set(s); });
   const unsigned w0 = (unsigned)cur.cg * (S3_NSTEP * S3_WSTEP);
@@ -460,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void conv_s3_kernel(S3ConvParams p) {
       // unconditional part of the step: weight ring, next tap position's fragments, staging
       if constexpr (s + 2 < S3_NSTEP) wload(std::integral_constant<int, s + 2>{}, wcur);
       else wload(std::integral_constant<int, s + 2 - S3_NSTEP>{}, wnext);
-      if constexpr (tp + 1 < 9) {
+      if constexpr (V == 0 && tp + 1 < 9) {
         if constexpr (kz == 0) {
           xload(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, 0>{}, rd);
           xload(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, 1>{}, rd);
@@ -471,33 +519,41 @@ __global__ __launch_bounds__(256, 1) void conv_s3_kernel(S3ConvParams p) {
       }
       if constexpr (s < S3_NPW) stg[s % 4] = buffer_load16(nrsrc, vx[s] >= nxmin ? voff[s] : OOBV, 0);
       if constexpr (s >= 3 && s - 3 < S3_NPW)
-        *reinterpret_cast<f32x4*>(wr + 4096 * (s - 3)) = stg[(s - 3) % 4];
+        if (piece_ok(s - 3)) *reinterpret_cast<f32x4*>(wr + 4096 * (s - 3)) = stg[(s - 3) % 4];
       __builtin_amdgcn_sched_barrier(0);
-      if (mask & (1u << kz)) {
-        constexpr int set = 2 - kz;
+      constexpr int set = 2 - kz;
+      auto row_mfmas = [&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        const bf16x8 xh_ = xq[tp & (XQ - 1)][r][0], xm = xq[tp & (XQ - 1)][r][1], xl = xq[tp & (XQ - 1)][r][2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bf16x8 xh_ = xq[tp & 1][r][0], xm = xq[tp & 1][r][1], xl = xq[tp & 1][r][2];
-#pragma unroll
-          for (int a = 0; a < 2; ++a) {
-            const bf16x8 wh = wq[s % 3][a][0], wm = wq[s % 3][a][1], wl = wq[s % 3][a][2];
-            f32x4 c = acc[set][r][a];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh_, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh_, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh_, c, 0, 0, 0);
-            acc[set][r][a] = c;
-          }
+        for (int a = 0; a < NA; ++a) {
+          const bf16x8 wh = wq[s % 3][a][0], wm = wq[s % 3][a][1], wl = wq[s % 3][a][2];
+          f32x4 c = acc[set][r][a];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh_, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh_, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh_, c, 0, 0, 0);
+          acc[set][r][a] = c;
         }
+      };
+      if constexpr (V == 1 && kz == 2 && tp + 1 < 9) {
+        static_for<0, 4>([&](auto rc) {
+          if (mask & (1u << kz)) row_mfmas(rc);
+          __builtin_amdgcn_sched_barrier(0);
+          xload(std::integral_constant<int, tp + 1>{}, rc, rd);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else {
+        if (mask & (1u << kz)) static_for<0, 4>(row_mfmas);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
     // the last pieces of the next image (steps 24..26 carried pieces 14..16 in flight)
     static_for<S3_NSTEP - 3, S3_NPW>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
-      *reinterpret_cast<f32x4*>(wr + 4096 * t) = stg[t % 4];
+      if (piece_ok(t)) *reinterpret_cast<f32x4*>(wr + 4096 * t) = stg[t % 4];
     });
     if (cur.cg == ncg - 1) {                                    // the plane is complete
       const int zo = cur.zi - 1;
@@ -505,7 +561,7 @@ __global__ __launch_bounds__(256, 1) void conv_s3_kernel(S3ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int a = 0; a < 2; ++a) { acc[0][r][a] = acc[1][r][a]; acc[1][r][a] = acc[2][r][a]; }
+        for (int a = 0; a < NA; ++a) { acc[0][r][a] = acc[1][r][a]; acc[1][r][a] = acc[2][r][a]; }
       zero_set(std::integral_constant<int, 2>{});
       if (cur.zi == cur.zhi) {                                  // segment ends
         if (cur.zhi >= cur.z0 && cur.zhi < cur.z1) emit(cur, cur.zhi);   // only when z1 = Di: no plane Di follows
@@ -516,6 +572,27 @@ __global__ __launch_bounds__(256, 1) void conv_s3_kernel(S3ConvParams p) {
     cur = nxt; img ^= 1;
     if (!cur.valid) break;
   }
+}
+
+template <int V>
+int launch_conv_s3(S3ConvParams p, const dsm_conv3d_s3_args* a, hipStream_t s) {
+  using C = S3Cfg<V>;
+  p.ntx = dsm_cdiv(a->Wo, 32); p.nty = dsm_cdiv(a->Ho, C::TY);
+  const long ncol = (long)a->B * p.nty * p.ntx;
+  DSM_REQUIRE(ncol < (1L << 30), DSM_ERR_UNSUPPORTED);
+  p.ncol = (int)ncol;
+  p.nunits = ncol * a->Do;
+  static thread_local bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute((const void*)conv_s3_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C::LDS) != hipSuccess)
+      return DSM_ERR_LAUNCH;
+    configured = true;
+  }
+  int blocks = a->grid > 0 ? a->grid : 256 * C::WGS;           // persistent workgroups: WGS per CU
+  if ((long)blocks > p.nunits) blocks = (int)p.nunits;
+  hipLaunchKernelGGL(conv_s3_kernel<V>, dim3(blocks), dim3(256), C::LDS, s, p);
+  return dsm_launch_status();
 }
 
 int check_s3_dims(int B, int C, int D, int H, int W) {
@@ -619,7 +696,7 @@ extern "C" int dsm_conv3d_s3_fwd(const dsm_conv3d_s3_args* a, dsm_stream_t strea
               DSM_ERR_ARG);
   DSM_REQUIRE(a->Cin > 0 && a->Cin % 32 == 0 && a->Cout == 32, DSM_ERR_UNSUPPORTED);
   DSM_REQUIRE(a->Do <= a->Di && a->Ho <= a->Hi && a->Wo <= a->Wi, DSM_ERR_ARG);
-  DSM_REQUIRE(a->relu >= 0 && a->relu <= 2, DSM_ERR_ARG);
+  DSM_REQUIRE(a->relu >= 0 && a->relu <= 2 && a->tiling >= 0 && a->tiling <= 2, DSM_ERR_ARG);
   if (a->vol_virtual) DSM_REQUIRE(a->Cin % 64 == 0, DSM_ERR_UNSUPPORTED);   // [left | right], 32-channel groups each
   if (a->residual)
     DSM_REQUIRE(a->Dr >= a->Do && a->Hr >= a->Ho && a->Wr >= a->Wo, DSM_ERR_ARG);
@@ -636,23 +713,9 @@ extern "C" int dsm_conv3d_s3_fwd(const dsm_conv3d_s3_args* a, dsm_stream_t strea
   p.Di = a->Di; p.Hi = a->Hi; p.Wi = a->Wi; p.Do = a->Do; p.Ho = a->Ho; p.Wo = a->Wo;
   p.Dr = a->Dr; p.Hr = a->Hr; p.Wr = a->Wr; p.relu = a->relu;
   p.vol = a->vol_virtual ? 1 : 0; p.vol_mask_left = a->vol_mask_left ? 1 : 0;
-  p.ntx = dsm_cdiv(a->Wo, 32); p.nty = dsm_cdiv(a->Ho, S3_TY);
-  const long ncol = (long)a->B * p.nty * p.ntx;
-  DSM_REQUIRE(ncol < (1L << 30), DSM_ERR_UNSUPPORTED);
-  p.ncol = (int)ncol;
-  p.nunits = ncol * a->Do;
   p.wbytes = (unsigned)dsm_conv3d_s3_packed_weight_bytes(a->Cin, 32);
-  hipStream_t s = (hipStream_t)stream;
   dsm_clear_stale_error();
-  static thread_local bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute((const void*)conv_s3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            S3_LDS) != hipSuccess)
-      return DSM_ERR_LAUNCH;
-    configured = true;
-  }
-  int blocks = a->grid > 0 ? a->grid : 256;                    // one persistent workgroup per CU
-  if ((long)blocks > p.nunits) blocks = (int)p.nunits;
-  hipLaunchKernelGGL(conv_s3_kernel, dim3(blocks), dim3(256), S3_LDS, s, p);
-  return dsm_launch_status();
+  const int tiling = a->tiling ? a->tiling : S3_DEFAULT_TILING;
+  if (tiling == 1) return launch_conv_s3<0>(p, a, (hipStream_t)stream);
+  return launch_conv_s3<1>(p, a, (hipStream_t)stream);
 }

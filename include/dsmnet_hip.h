@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DSM_ABI_VERSION 4
+#define DSM_ABI_VERSION 5
 
 #define DSM_OK               0
 #define DSM_ERR_ARG         -1   /* null pointer, non-positive size, bad enum      */
@@ -208,6 +208,13 @@ int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, in
                      int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int stride,
                      dsm_stream_t stream);
 
+/* (ABI v5) The same for the 2-D towers' 3x3 layers -- autograd through convbn / BasicBlock
+ * (models/psmnet/submodule.py:10-13,24-46) when the feature extraction trains.  padding = dilation;
+ * (stride, dilation) in {(1,1), (1,2), (2,1)}.  x: (B,Hx,Wx,Cx) NHWC, g: (B,Hg,Wg,Cg) NHWC;
+ * ws: (Cx/32)*(Cg/32)*9*32*32 floats (zeroed here); dw: (Cg, Cx, 3, 3) torch layout, overwritten. */
+int dsm_conv2d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, int Cx, int Cg,
+                     int Hx, int Wx, int Hg, int Wg, int stride, int dilation, dsm_stream_t stream);
+
 /* Cout = 1, stride 1 (classifier heads): g (B,D,H,W); x (B,D,H,W,C); w_packed [27][C];
  * dx (B,D,H,W,C) or NULL; dw_tapmajor [27][C] or NULL (the caller transposes to (1,C,27)). */
 int dsm_conv3d_cout1_bwd(const void* x, const void* g, const void* w_packed, void* dx,
@@ -276,6 +283,9 @@ typedef struct dsm_conv3d_s3_args {
    * the first 3-D convolution.  Di = the number of disparity planes. */
   int vol_virtual;
   int vol_mask_left;
+  /* ABI v5.  0 = the library's default; 1 = 8 x 32 output tile, one workgroup per CU; 2 = 4 x 32 tile, two
+   * workgroups per CU.  Same arithmetic and results either way (speed only). */
+  int tiling;
 } dsm_conv3d_s3_args;
 /* split feature maps for a virtual volume: fL, fR (B,C,H,W) NCHW fp32 -> fs,
  * dsm_concat_volume_s3_scratch_bytes(B,C,H,W) bytes. */

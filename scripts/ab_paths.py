@@ -1,5 +1,5 @@
 """Same-process A/B of the PSMNet eval forward with host-side options toggled (interleaved rounds):
-    s3 on/off, fuse_volume on/off, and optional per-stage breakdown from the LaunchTimer."""
+    s3 on/off, fuse_volume on/off, the S3 kernel's two tilings, and optional per-stage breakdown from the LaunchTimer."""
 import sys
 import time
 
@@ -18,15 +18,17 @@ l, r = torch.rand(1, 3, H, W, generator=g).to(dev), torch.rand(1, 3, H, W, gener
 calibrate.calibrate_batchnorm(m, l, r)
 calibrate.calibrate_psmnet_heads(m, l, r)
 m.eval()
-configs = {"s3+fuse": (True, True), "s3": (True, False), "r01": (False, False)}  # (s3, fuse_volume); s3in stays off
+# (s3, fuse_volume, s3_tiling); s3in stays off
+configs = {"s3+fuse": (True, True, 0), "s3": (True, False, 0), "r01": (False, False, 0),
+           "tile8x32": (True, True, 1), "tile4x32": (True, True, 2)}
 if len(sys.argv) > 1:
     configs = {k: v for k, v in configs.items() if k in sys.argv[1:]}
 res = {k: [] for k in configs}
 stages = {}
 with torch.no_grad():
     for rnd in range(6):
-        for name, (s3, fuse) in configs.items():
-            cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse)
+        for name, (s3, fuse, tiling) in configs.items():
+            cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse), cv.set_option("s3_tiling", tiling)
             for _ in range(2):
                 m(l, r)
             torch.cuda.synchronize()
@@ -36,8 +38,8 @@ with torch.no_grad():
             torch.cuda.synchronize()
             if rnd:
                 res[name].append((time.perf_counter() - t0) / 10 * 1e3)
-    for name, (s3, fuse) in configs.items():
-        cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse)
+    for name, (s3, fuse, tiling) in configs.items():
+        cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse), cv.set_option("s3_tiling", tiling)
         t = cv.LaunchTimer()
         cv.set_timer(t)
         for _ in range(5):

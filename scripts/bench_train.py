@@ -15,10 +15,15 @@ m = model_create_by_name("psmnet", 192).cuda().train()
 for i in (1, 2, 3):
     with torch.no_grad():
         getattr(m, "classif%d" % i)[2].weight.mul_(1e-3)
+import os
+for pat in [q for q in os.environ.get("DSM_BENCH_FREEZE", "").split(",") if q]:   # attribution runs
+    for n, q in m.named_parameters():
+        if pat in n:
+            q.requires_grad_(False)
 left = torch.rand(B, 3, H, W, device="cuda")
 right = torch.roll(left, -6, dims=3)
 target = torch.full((B, H, W), 6.0, device="cuda")
-opt = torch.optim.SGD(m.parameters(), lr=1e-4)
+opt = torch.optim.SGD([q for q in m.parameters() if q.requires_grad], lr=1e-4)
 
 
 def step():
@@ -66,7 +71,7 @@ from dsmnet_amd.graphs import GraphedTrainStep
 batch = torch.cat([left, right, target.unsqueeze(1)], 1)
 lossfun = train.losses("supervised", 1, 0)
 lossfun.Weight_Adjust_levels(0)
-gopt = torch.optim.Adam(m.parameters(), lr=1e-4, capturable=True)
+gopt = torch.optim.Adam([q for q in m.parameters() if q.requires_grad], lr=1e-4, capturable=True)
 gstep = GraphedTrainStep(m, gopt, lossfun, batch)
 gstep(batch); torch.cuda.synchronize()
 a.record()

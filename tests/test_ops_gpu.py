@@ -137,6 +137,8 @@ def test_softargmin_golden_cases(cv, golden_ops):
     ((2, 1, 12, 9, 17), (48, 35, 66), False, False),     # non-integer scale factors
     ((1, 1, 12, 8, 16), (48, 32, 64), False, True),      # PyTorch-0.3 era align_corners
     ((1, 1, 5, 6, 70), (7, 6, 300), False, False),       # D < 8: fewer lane segments
+    ((1, 1, 25, 7, 11), (100, 27, 45), False, False),    # D >= 96: four disparity segments in the tiled adjoint
+    ((2, 1, 24, 5, 9), (96, 20, 36), False, True),
     ((1, 1, 48, 12, 20), None, True, False),             # GCNet form
     ((2, 1, 192, 5, 33), None, True, False),
 ])
