@@ -69,8 +69,8 @@ SIGNATURES = {
     "dsm_conv_pack_weights_s3in": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "dsm_conv3d_fwd": (c_int, [ctypes.POINTER(Conv3dArgs), c_void_p]),
     "dsm_conv3d_plan": (c_int, [ctypes.POINTER(Conv3dArgs), ctypes.c_char_p, c_int]),
-    "dsm_conv3d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
-    "dsm_conv2d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
+    "dsm_conv3d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p]),
+    "dsm_conv2d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     "dsm_conv3d_cout1_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "dsm_deconv3d_cout1_bwd": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "dsm_s3_bytes": (c_size_t, [c_int] * 5),

@@ -776,12 +776,12 @@ def _wgrad(x_cl, g_cl, cx, cg, stride):
     B = x_cl.shape[0]
     ws = torch.empty((cx // 32) * (cg // 32) * 27 * 1024, device=x_cl.device, dtype=torch.float32)
     dw = torch.empty((cg, cx, 3, 3, 3), device=x_cl.device, dtype=torch.float32)
-    with torch.cuda.device(x_cl.device), _timed("conv3d_wgrad_kernel", 54.0 * cx * cg * B *
+    with torch.cuda.device(x_cl.device), _timed("conv3d_wgrad_kernel<S=%d,%dx%d>" % (stride, cx, cg), 54.0 * cx * cg * B *
                                                 g_cl.shape[2] * g_cl.shape[3] * g_cl.shape[4]):
         rc = _lib.load().dsm_conv3d_wgrad(_p(x_cl), _p(g_cl), _p(ws), _p(dw), B, cx, cg,
                                           x_cl.shape[2], x_cl.shape[3], x_cl.shape[4],
                                           g_cl.shape[2], g_cl.shape[3], g_cl.shape[4], stride,
-                                          _stream())
+                                          _conv_flags(), _stream())
     _lib.check(rc, "dsm_conv3d_wgrad")
     return dw
 
@@ -963,7 +963,7 @@ def _wgrad2d(x_cl, g_cl, stride, dilation):
     dw = torch.empty((cg, cx, 3, 3), device=x_cl.device, dtype=torch.float32)
     with torch.cuda.device(x_cl.device), _timed("conv2d_wgrad_kernel", 18.0 * cx * cg * B * Hg * Wg):
         rc = _lib.load().dsm_conv2d_wgrad(_p(x_cl), _p(g_cl), _p(ws), _p(dw), B, cx, cg, Hx, Wx,
-                                          Hg, Wg, int(stride), int(dilation), _stream())
+                                          Hg, Wg, int(stride), int(dilation), _conv_flags(), _stream())
     _lib.check(rc, "dsm_conv2d_wgrad")
     return dw
 

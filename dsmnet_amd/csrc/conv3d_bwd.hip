@@ -107,9 +107,10 @@ __global__ __launch_bounds__(NT_, 1) void conv3d_wgrad_kernel(WgradParams p) {
       if (tap < NTAP) {
         const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
         const float* xa = xf + ((dz * IY + dy * DIL) * IX + dx * DIL) * 32 + r;   // + voxel*32*S...
-        const int k0 = KZ == 3 ? 0 : wave * (TY * 4), k1 = KZ == 3 ? TY * 16 : k0 + TY * 4;
+        const int k0 = KZ == 3 ? 0 : wave * (TY * 4);
 #pragma unroll 4
-        for (int kk = k0; kk < k1; ++kk) {
+        for (int ki = 0; ki < (KZ == 3 ? TY * 16 : TY * 4); ++ki) {
+          const int kk = k0 + ki;
           const int vy = kk >> 4, vx = ((kk & 15) << 1) + h;              // voxel of this lane's k
           const float av = xa[((vy * S) * IX + vx * S) * 32];
           const float bv = gf[(vy * 32 + vx) * 32 + r];
@@ -117,6 +118,260 @@ __global__ __launch_bounds__(NT_, 1) void conv3d_wgrad_kernel(WgradParams p) {
         }
       }
     });
+  }
+  // flush: ws[pair][tap][c][g] += acc  (row = c, column = g on the lanes)
+  sfor<0, NACC>([&](auto ac) {
+    constexpr int a = decltype(ac)::value;
+    const int tap = KZ == 3 ? wave + 4 * a : a;
+    if (tap < NTAP) {
+      float* dst = p.ws + (((long)pair * NTAP + tap) * 32) * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = (i & 3) + 8 * (i >> 2) + 4 * h;
+        atomicAdd(dst + c * 32, acc[a][i]);
+      }
+    }
+  });
+}
+
+// ---- the same reduction on the bf16 pipe (bf16x3: fp32 operands split into three bf16 terms, six
+// cross products per MAC, fp32 accumulation -- DESIGN.md 3.2a) --------------------------------
+// v_mfma_f32_32x32x16_bf16 wants, per lane, EIGHT CONSECUTIVE k (= voxels) of one channel, while
+// NDHWC memory (and any sane staging pass) has a voxel's channels consecutive.  gfx950's transposed
+// LDS read closes the gap: the tiles are staged as [plane][voxel][32 channels] bf16 (64-byte rows,
+// one ds_write_b64 per plane per staged f32x4) and ds_read_b64_tr_b16 hands lane (channel) four
+// voxels per read -- and since every lane supplies its own row address, the tap shift (any dx, any
+// stride) is just another row offset: no shifted copies, no alignment cases.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef short ws16x4 __attribute__((ext_vector_type(4)));
+typedef short ws16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned wu32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wsplit4(const f32x4 v, wu32x2 (&pl)[3]) {
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    unsigned u[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f2 t = {r[2 * i], r[2 * i + 1]};
+      u[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, b2));
+      if (k < 2) {
+        r[2 * i] -= __builtin_bit_cast(float, u[i] << 16);
+        r[2 * i + 1] -= __builtin_bit_cast(float, u[i] & 0xffff0000u);
+      }
+    }
+    pl[k] = wu32x2{u[0], u[1]};
+  }
+}
+
+// eight voxels (rows row0 .. row0 + 7*RS, RS rows apart) of this lane's channel: two transposed reads
+template <int RS>
+__device__ __forceinline__ wbf16x8 tr_frag(const unsigned char* lane_base, int byte_off) {
+  typedef __attribute__((address_space(3))) ws16x4 lds_s16x4;
+  const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lane_base + byte_off));
+  const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lane_base + byte_off + 4 * RS * 64));
+  const ws16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(wbf16x8, v);
+}
+
+template <int S, int TY, int KZ, int DIL>
+struct WgradGeo {
+  static constexpr int IY = (TY - 1) * S + 2 * DIL + 1, IX = 31 * S + 2 * DIL + 1, IZ = KZ;
+  static constexpr int NXV = IZ * IY * IX, NGV = TY * 32;          // voxels of the X halo tile / G tile
+  static constexpr int XPL = NXV * 64, GPL = NGV * 64;             // plane strides, bytes
+  static constexpr int NTAP = 9 * KZ, NACC = KZ == 3 ? 7 : 9;
+  static constexpr size_t LDS = 3 * (size_t)(XPL + GPL);
+};
+
+template <int S, int TY, int KZ, int DIL>
+__global__ __launch_bounds__(NT_, 1) void wgrad_bf16x3_kernel(WgradParams p) {
+  using G = WgradGeo<S, TY, KZ, DIL>;
+  constexpr int IY = G::IY, IX = G::IX, NXV = G::NXV, NGV = G::NGV, XPL = G::XPL, GPL = G::GPL;
+  constexpr int NTAP = G::NTAP, NACC = G::NACC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
+  unsigned char* const xt = wl;                    // [plane][voxel (z, y, x)][32 ch] bf16
+  unsigned char* const gt = wl + 3 * XPL;          // [plane][voxel (y, x)][32 ch] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int pair = blockIdx.y;
+  const int ct = pair / (p.Cg / 32), gtile = pair % (p.Cg / 32);
+  // transposed-read lane roles: 16-lane group = (channel block cb, k half kg); lane 4 q + pp of the
+  // group addresses row q, channels 4 pp .. 4 pp + 3 of the 4-row x 16-channel block
+  const int grp = lane >> 4, cb = grp & 1, kg = grp >> 1, q4 = (lane & 15) >> 2, pp = lane & 3;
+  const unsigned char* const xlane = xt + ((8 * kg + q4) * S) * 64 + cb * 32 + pp * 8;
+  const unsigned char* const glane = gt + (8 * kg + q4) * 64 + cb * 32 + pp * 8;
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+  // Work: the (column, z) units z-fastest, one contiguous range per workgroup, so that a step along z
+  // re-stages only the X planes that are new (KZ = 3: one of three at stride 1, two at stride 2).  X
+  // plane zi lives in slot zi mod 3 of the tile.  The planes a z-step brings in (the last NSL of the
+  // tile) and the G tile are PREFETCHED: their global loads are issued before the previous tile's MFMA
+  // loop and split / written to LDS after it; the extra planes of a range's first tile are staged on
+  // the spot.
+  constexpr int NSL = KZ == 3 ? S : 1;
+  constexpr int PE = IY * IX * 8;                  // f32x4 elements of one X plane
+  constexpr int NXR = (PE + NT_ - 1) / NT_, NGR = (NGV * 8 + NT_ - 1) / NT_;
+  struct Tile { int b, ty0, tx0, tz, zlo, col; };
+  auto tile_at = [&](long u) {
+    Tile T;
+    T.col = (int)(u / p.Dg); T.tz = (int)(u % p.Dg);
+    int id = T.col;
+    T.tx0 = (id % p.ntx) * 32; id /= p.ntx;
+    T.ty0 = (id % p.nty) * TY; T.b = id / p.nty;
+    T.zlo = T.tz * S - KZ / 2;
+    return T;
+  };
+  auto load_plane = [&](const Tile& T, int zi, f32x4 (&dst)[NXR]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NXR; ++i) {
+      const int e = tid + i * NT_;
+      const int q = e & 7, v = e >> 3;
+      const int xx = v % IX, yy = v / IX;
+      const int yi = T.ty0 * S - DIL + yy, xi = T.tx0 * S - DIL + xx;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (e < PE && zi >= 0 && zi < p.Dx && yi >= 0 && yi < p.Hx && xi >= 0 && xi < p.Wx)
+        val = *reinterpret_cast<const f32x4*>(
+            p.x + ((((long)T.b * p.Dx + zi) * p.Hx + yi) * p.Wx + xi) * p.Cx + ct * 32 + q * 4);
+      dst[i] = val;
+    }
+  };
+  auto store_plane = [&](int zi, const f32x4 (&src)[NXR]) __attribute__((always_inline)) {
+    const int slot = KZ == 3 ? (zi + 3) % 3 : 0;
+#pragma unroll
+    for (int i = 0; i < NXR; ++i) {
+      const int e = tid + i * NT_;
+      if (e < PE) {
+        wu32x2 pl[3];
+        wsplit4(src[i], pl);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          *reinterpret_cast<wu32x2*>(xt + k * XPL + (slot * (IY * IX) + (e >> 3)) * 64 + (e & 7) * 8) = pl[k];
+      }
+    }
+  };
+  auto load_g = [&](const Tile& T, f32x4 (&dst)[NGR]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NGR; ++i) {
+      const int e = tid + i * NT_;
+      const int q = e & 7, v = e >> 3;
+      const int yi = T.ty0 + (v >> 5), xi = T.tx0 + (v & 31);
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (e < NGV * 8 && yi < p.Hg && xi < p.Wg)
+        val = *reinterpret_cast<const f32x4*>(
+            p.g + ((((long)T.b * p.Dg + T.tz) * p.Hg + yi) * p.Wg + xi) * p.Cg + gtile * 32 + q * 4);
+      dst[i] = val;
+    }
+  };
+  auto store_g = [&](const f32x4 (&src)[NGR]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NGR; ++i) {
+      const int e = tid + i * NT_;
+      if (e < NGV * 8) {
+        wu32x2 pl[3];
+        wsplit4(src[i], pl);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<wu32x2*>(gt + k * GPL + (e >> 3) * 64 + (e & 7) * 8) = pl[k];
+      }
+    }
+  };
+  const long nunits = (long)p.ntiles;              // = columns x Dg
+  const long u0 = nunits * blockIdx.x / gridDim.x, u1 = nunits * (blockIdx.x + 1) / gridDim.x;
+  if (u0 >= u1) return;
+  f32x4 xr[NSL][NXR], gr[NGR];
+  Tile cur = tile_at(u0);
+#pragma unroll
+  for (int j = 0; j < NSL; ++j) load_plane(cur, cur.zlo + KZ - NSL + j, xr[j]);
+  load_g(cur, gr);
+  int prev_col = -1, prev_hi = -0x40000000;        // column and highest X plane staged last
+  for (long u = u0; u < u1; ++u) {
+    const int zlo = cur.zlo;
+    const int znew = (cur.col == prev_col && prev_hi >= zlo) ? prev_hi + 1 : zlo;   // first plane to stage
+    prev_col = cur.col; prev_hi = zlo + KZ - 1;
+    // byte offset of tap a's first voxel in the X tile (wave-uniform)
+    int xtap[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      const int tap_ = KZ == 3 ? wave + 4 * a : a;
+      const int tap = tap_ < NTAP ? tap_ : 0;      // a slot past the last tap repeats tap 0 (never flushed)
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      const int slot = KZ == 3 ? (zlo + dz + 3) % 3 : 0;
+      xtap[a] = __builtin_amdgcn_readfirstlane(((slot * IY + dy * DIL) * IX + dx * DIL) * 64);
+    }
+    __syncthreads();
+    for (int zi = znew; zi < zlo + KZ - NSL; ++zi) {      // a range's first tile: the older planes too
+      f32x4 tmp[NXR];
+      load_plane(cur, zi, tmp);
+      store_plane(zi, tmp);
+    }
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) store_plane(zlo + KZ - NSL + j, xr[j]);
+    store_g(gr);
+    __syncthreads();
+    Tile nxt = cur;
+    if (u + 1 < u1) {
+      nxt = tile_at(u + 1);
+#pragma unroll
+      for (int j = 0; j < NSL; ++j) load_plane(nxt, nxt.zlo + KZ - NSL + j, xr[j]);
+      load_g(nxt, gr);
+    }
+    // k-blocks of 16 voxels along x: (row vy, half xb).  KZ = 3: every wave walks all of them for its
+    // own taps; KZ = 1: a wave takes a quarter of them for all nine taps.  The fragments of step
+    // (kb, a + 1) -- or (kb + 1, 0) with that block's G fragments -- are read while the six MFMAs of
+    // step (kb, a) run.  A tap slot past the last tap (wave 3's seventh at KZ = 3) repeats tap 0 into
+    // an accumulator nobody flushes: no branch in the loop.
+    constexpr int NKB = TY * 2;
+    const int kb0 = KZ == 3 ? 0 : wave * (NKB / 4), kb1 = KZ == 3 ? NKB : kb0 + NKB / 4;
+    auto xoff_of = [&](int kb) { return (((kb >> 1) * S) * IX + 16 * (kb & 1) * S) * 64; };
+    wbf16x8 xf[2][3], gf[2][3];
+    auto read_x = [&](wbf16x8 (&d)[3], int o) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) d[k] = tr_frag<S>(xlane, o + k * XPL);
+    };
+    auto read_g = [&](wbf16x8 (&d)[3], int kb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) d[k] = tr_frag<1>(glane, kb * 1024 + k * GPL);
+    };
+    read_g(gf[0], kb0);
+    read_x(xf[0], xoff_of(kb0) + xtap[0]);
+    static_assert(NKB % 2 == 0 && (KZ == 3 || (NKB / 4) % 2 == 0), "k-blocks are walked in pairs");
+    for (int kb2 = kb0; kb2 < kb1; kb2 += 2) {
+      sfor<0, 2>([&](auto kc) {
+        constexpr int par = decltype(kc)::value;    // G fragment buffer of this k-block
+        const int kb = kb2 + par;
+        const int kbn = kb + 1 < kb1 ? kb + 1 : kb; // the last block re-reads itself (discarded)
+        const int xoff = xoff_of(kb), xoffn = xoff_of(kbn);
+        sfor<0, NACC>([&](auto ac) {
+          constexpr int a = decltype(ac)::value;
+          constexpr int xp = (a + NACC * par) & 1;  // X fragment buffer of step (kb, a): NACC is odd
+          static_assert(NACC % 2 == 1, "");
+          if constexpr (a + 1 < NACC) {
+            read_x(xf[xp ^ 1], xoff + xtap[a + 1]);
+          } else {
+            read_g(gf[par ^ 1], kbn);
+            read_x(xf[xp ^ 1], xoffn + xtap[0]);
+          }
+          __builtin_amdgcn_sched_barrier(0);         // the next step's reads stay ahead of these MFMAs
+          const wbf16x8 xh = xf[xp][0], xm = xf[xp][1], xlo = xf[xp][2];
+          const wbf16x8 gh = gf[par][0], gm = gf[par][1], glo = gf[par][2];
+          f32x16 c = acc[a];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, gm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xlo, gh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, glo, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, gh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, gm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, gh, c, 0, 0, 0);
+          acc[a] = c;
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+    }
+    cur = nxt;
   }
   // flush: ws[pair][tap][c][g] += acc  (row = c, column = g on the lanes)
   sfor<0, NACC>([&](auto ac) {
@@ -144,6 +399,33 @@ __global__ void wgrad_permute_kernel(const float* __restrict__ ws, float* __rest
   const int g = i / ((long)ntap * Cx);
   const int pair = (c / 32) * (Cg / 32) + g / 32;
   dw[i] = ws[(((long)pair * ntap + tap) * 32 + (c & 31)) * 32 + (g & 31)];
+}
+
+template <int S, int TY, int KZ, int DIL>
+int launch_wgrad_bf16x3(WgradParams p, float* dw, hipStream_t s) {
+  using G = WgradGeo<S, TY, KZ, DIL>;
+  static_assert(G::LDS <= 160 * 1024, "LDS");
+  static_assert(KZ == 3 || (TY * 2) % 4 == 0, "KZ = 1 splits the k-blocks over the four waves");
+  const size_t wsbytes = (size_t)p.npair * G::NTAP * 32 * 32 * sizeof(float);
+  if (hipMemsetAsync(p.ws, 0, wsbytes, s) != hipSuccess) return DSM_ERR_LAUNCH;
+  p.ntx = dsm_cdiv(p.Wg, 32); p.nty = dsm_cdiv(p.Hg, TY);
+  const long nt = (long)p.B * p.Dg * p.nty * p.ntx;
+  DSM_REQUIRE(nt < (1L << 30), DSM_ERR_UNSUPPORTED);
+  p.ntiles = (int)nt;
+  int bx = 256 / p.npair; if (bx < 1) bx = 1;
+  if (bx > p.ntiles) bx = p.ntiles;
+  static thread_local bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute((const void*)wgrad_bf16x3_kernel<S, TY, KZ, DIL>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS) != hipSuccess)
+      return DSM_ERR_LAUNCH;
+    configured = true;
+  }
+  hipLaunchKernelGGL((wgrad_bf16x3_kernel<S, TY, KZ, DIL>), dim3(bx, p.npair), dim3(NT_), G::LDS, s, p);
+  const long n = (long)p.Cx * p.Cg * G::NTAP;
+  hipLaunchKernelGGL(wgrad_permute_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s,
+                     (const float*)p.ws, dw, p.Cx, p.Cg, G::NTAP);
+  return dsm_launch_status();
 }
 
 template <int S, int TY, int KZ, int DIL>
@@ -372,7 +654,7 @@ __global__ __launch_bounds__(256) void deconv_cout1_bwd_weight_kernel(
 // ws: workspace of (Cx/32)*(Cg/32)*27*32*32 floats (zeroed here); dw: (Cg, Cx, 27), overwritten.
 extern "C" int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, int Cx,
                                 int Cg, int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int stride,
-                                dsm_stream_t stream) {
+                                int flags, dsm_stream_t stream) {
   DSM_REQUIRE(x && g && ws && dw, DSM_ERR_ARG);
   DSM_REQUIRE(B > 0 && Cx > 0 && Cg > 0 && Dx > 0 && Hx > 0 && Wx > 0 && Dg > 0 && Hg > 0 && Wg > 0,
               DSM_ERR_ARG);
@@ -385,6 +667,10 @@ extern "C" int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw
   p.x = (const float*)x; p.g = (const float*)g; p.ws = (float*)ws;
   p.B = B; p.Cx = Cx; p.Cg = Cg; p.Dx = Dx; p.Hx = Hx; p.Wx = Wx; p.Dg = Dg; p.Hg = Hg; p.Wg = Wg;
   p.npair = (Cx / 32) * (Cg / 32);
+  if (!(flags & DSM_CONV_FP32_MFMA)) {             // fp32 on the bf16 pipe (bf16x3)
+    if (stride == 1) return launch_wgrad_bf16x3<1, 4, 3, 1>(p, (float*)dw, s);
+    return launch_wgrad_bf16x3<2, 1, 3, 1>(p, (float*)dw, s);
+  }
   if (stride == 1) return launch_wgrad<1, 4, 3, 1>(p, (float*)dw, s);
   return launch_wgrad<2, 2, 3, 1>(p, (float*)dw, s);
 }
@@ -393,7 +679,7 @@ extern "C" int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw
 // g: (B,Hg,Wg,Cg); ws: (Cx/32)*(Cg/32)*9*32*32 floats; dw: (Cg, Cx, 3, 3), overwritten.
 extern "C" int dsm_conv2d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, int Cx,
                                 int Cg, int Hx, int Wx, int Hg, int Wg, int stride, int dilation,
-                                dsm_stream_t stream) {
+                                int flags, dsm_stream_t stream) {
   DSM_REQUIRE(x && g && ws && dw, DSM_ERR_ARG);
   DSM_REQUIRE(B > 0 && Cx > 0 && Cg > 0 && Hx > 0 && Wx > 0 && Hg > 0 && Wg > 0, DSM_ERR_ARG);
   DSM_REQUIRE((stride == 1 && (dilation == 1 || dilation == 2)) || (stride == 2 && dilation == 1),
@@ -406,6 +692,11 @@ extern "C" int dsm_conv2d_wgrad(const void* x, const void* g, void* ws, void* dw
   p.x = (const float*)x; p.g = (const float*)g; p.ws = (float*)ws;
   p.B = B; p.Cx = Cx; p.Cg = Cg; p.Dx = 1; p.Hx = Hx; p.Wx = Wx; p.Dg = 1; p.Hg = Hg; p.Wg = Wg;
   p.npair = (Cx / 32) * (Cg / 32);
+  if (!(flags & DSM_CONV_FP32_MFMA)) {
+    if (stride == 2) return launch_wgrad_bf16x3<2, 4, 1, 1>(p, (float*)dw, s);
+    if (dilation == 2) return launch_wgrad_bf16x3<1, 8, 1, 2>(p, (float*)dw, s);
+    return launch_wgrad_bf16x3<1, 8, 1, 1>(p, (float*)dw, s);
+  }
   if (stride == 2) return launch_wgrad<2, 4, 1, 1>(p, (float*)dw, s);
   if (dilation == 2) return launch_wgrad<1, 8, 1, 2>(p, (float*)dw, s);
   return launch_wgrad<1, 8, 1, 1>(p, (float*)dw, s);

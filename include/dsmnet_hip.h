@@ -203,9 +203,12 @@ int dsm_conv3d_plan(const dsm_conv3d_args* args, char* buf, int len);
  *   ConvTranspose3d(s=2):  X = dY, G = layer input, stride 2 -> dw is (Cin, Cout, 3,3,3)
  * ws: scratch of (Cx/32)*(Cg/32)*27*1024 floats; dw: Cg*Cx*27 floats, overwritten.
  * Channels must be multiples of 32.  Sums are accumulated with fp32 atomics (order varies).
+ * flags (ABI v5): DSM_CONV_FP32_MFMA keeps the exact fp32-input MFMA kernel; 0 = fp32 operands on
+ * the bf16 pipe (bf16x3, as the forward kernels), staged once as [voxel][channel] bf16 planes and
+ * read through gfx950's transposed LDS read.
  * ------------------------------------------------------------------------- */
 int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, int Cx, int Cg,
-                     int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int stride,
+                     int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int stride, int flags,
                      dsm_stream_t stream);
 
 /* (ABI v5) The same for the 2-D towers' 3x3 layers -- autograd through convbn / BasicBlock
@@ -213,7 +216,8 @@ int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, in
  * (stride, dilation) in {(1,1), (1,2), (2,1)}.  x: (B,Hx,Wx,Cx) NHWC, g: (B,Hg,Wg,Cg) NHWC;
  * ws: (Cx/32)*(Cg/32)*9*32*32 floats (zeroed here); dw: (Cg, Cx, 3, 3) torch layout, overwritten. */
 int dsm_conv2d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, int Cx, int Cg,
-                     int Hx, int Wx, int Hg, int Wg, int stride, int dilation, dsm_stream_t stream);
+                     int Hx, int Wx, int Hg, int Wg, int stride, int dilation, int flags,
+                     dsm_stream_t stream);
 
 /* Cout = 1, stride 1 (classifier heads): g (B,D,H,W); x (B,D,H,W,C); w_packed [27][C];
  * dx (B,D,H,W,C) or NULL; dw_tapmajor [27][C] or NULL (the caller transposes to (1,C,27)). */

@@ -269,3 +269,26 @@ def test_gcnet_train_step(hip_lib):
     losses = [train.train_step(model, opt, lossfun, batch)[0] for _ in range(4)]
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("stride,shape", [(1, (1, 6, 12, 40)), (2, (1, 5, 9, 37))])
+def test_wgrad_exact_fp32_kernel_option(cv, stride, shape):
+    """``conv_fp32`` (DSM_CONV_FP32_MFMA in the wgrad flags) keeps the fp32-input MFMA weight-gradient
+    kernel; both kernels agree with the fp64 reference."""
+    B, D, H, W = shape
+    x = seeded(1, B, 32, D, H, W)
+    w = seeded(2, 64, 32, 3, 3, 3, scale=0.1).requires_grad_(True)
+    ref = F.conv3d(x.double(), w.double(), None, stride=stride, padding=1)
+    cot = seeded(4, *ref.shape)
+    (gref,) = torch.autograd.grad(ref, [w], cot.double())
+    got = {}
+    for exact in (False, True):
+        old = cv.set_option("conv_fp32", exact)
+        try:
+            wg = w.detach().cuda().requires_grad_(True)
+            y = cv.conv3d(x.cuda(), wg, None, stride, False)
+            (got[exact],) = torch.autograd.grad(y, [wg], cot.cuda())
+        finally:
+            cv.set_option("conv_fp32", old)
+    tol = 1e-3 * max(1.0, gref.abs().max().item())
+    assert maxerr(got[False], gref.float()) <= tol and maxerr(got[True], gref.float()) <= tol
