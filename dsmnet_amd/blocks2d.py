@@ -22,7 +22,9 @@ from .blocks3d import _versions
 # fused path is correct (tests/test_conv2d_bwd_gpu.py) but SLOWER -- 38.0 vs 29.8 ms per replayed step
 # (DESIGN.md section 9): ~1,500 launches of 4-16 us each, tiles that fill a quarter of the CUs, and a
 # weight-gradient kernel that spends its time in atomics at these sizes.
-_FUSED_TRAIN_2D = __import__("os").environ.get("DSM_TRAIN_2D", "stock") == "fused"
+_TRAIN_2D_MODE = __import__("os").environ.get("DSM_TRAIN_2D", "stock")
+_FUSED_TRAIN_2D = _TRAIN_2D_MODE in ("fused", "conv")
+_FUSED_TRAIN_2D_BN = _TRAIN_2D_MODE == "fused"      # "conv": own convolutions, stock BatchNorm2d
 
 
 def s3in_ok(conv):
@@ -131,7 +133,8 @@ def _run_conv2d_autograd(conv, bn, x, residual, relu):
     each way (csrc/bn3d.hip on the (B, C, 1, H, W) view) -- instead of nn.Conv2d + nn.BatchNorm2d +
     add + ReLU and their autograd nodes (models/psmnet/submodule.py:10-13,24-46)."""
     y = cv.conv2d(x, conv.weight, conv.stride[0], conv.dilation[0])
-    if bn is not None and bn.training and blocks3d._FUSED_TRAIN_BN and y.shape[1] % 4 == 0 and y.shape[1] <= 256:
+    if (bn is not None and bn.training and _FUSED_TRAIN_2D_BN and blocks3d._FUSED_TRAIN_BN and
+            y.shape[1] % 4 == 0 and y.shape[1] <= 256):
         momentum = bn.momentum if bn.momentum is not None else 0.1
         out = cv.bn_add_relu2d(y, bn.weight, bn.bias, residual,
                                bn.running_mean if bn.track_running_stats else None,

@@ -52,13 +52,15 @@ class GraphedTrainStep(object):
     """One supervised training step -- train-mode forward, pyramid loss, backward, optimizer step
     (``train.train_step`` without its host-side metrics) -- captured once and replayed.
 
-    A PSMNet step is ~2,300 kernel launches.  Measured at 256x512 on an idle host the replay
-    takes as long as eager launches (32.5 vs 32.4 ms: the step is GPU-bound, 8.9 ms of it in this
-    library's kernels); what the graph buys is independence from the host when several ranks
-    share it.  ``step = GraphedTrainStep(model, optim, lossfun, batch)``;
+    A PSMNet step is ~3,000 kernel launches, most of them stock torch / MIOpen kernels of ~5 us for
+    the train-mode 2-D towers; on an idle host the replay takes about as long as eager launches, and
+    what the graph buys is independence from the host when several ranks share it.
+    ``step = GraphedTrainStep(model, optim, lossfun, batch)``;
     ``loss, disps = step(next_batch)`` (static tensors).
-    The optimizer must be built with ``capturable=True``; single process only (a captured
-    gradient all-reduce is not wired up).
+    The optimizer must be built with ``capturable=True``; build it with ``fused=True`` as well: the
+    capturable foreach Adam issues ~4 tiny kernels per parameter tensor (518 divisions and 145
+    counter increments per PSMNet step, 3 ms of a 27 ms step at 256x512 -- DESIGN.md section 9).
+    Single process only (a captured gradient all-reduce is not wired up).
 
     An eager backward through the same model before the capture leaves gradient tensors and
     autograd buffers that were allocated OUTSIDE the capture's private pool, on the default

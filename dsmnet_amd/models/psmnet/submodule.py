@@ -15,6 +15,11 @@ from ... import costvolume as cv
 from ...blocks2d import ConvBN2d, _Folded2d, run_conv2d, s3in_ok, s3out_ok, stage_image_nhwc16
 from ...blocks3d import ConvBN3d, _versions
 
+# DSM_TRAIN_SPP=interp (read by this host module) keeps F.interpolate under autograd (A/B runs)
+_SPP_MATMUL = __import__("os").environ.get("DSM_TRAIN_SPP", "matmul") != "interp"
+# DSM_TRAIN_LAYOUT=nhwc: the stock train-mode tower layers run on channels_last maps (A/B runs)
+_TRAIN_NHWC = __import__("os").environ.get("DSM_TRAIN_LAYOUT", "nchw") == "nhwc"
+
 
 def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
     # the reference pads by `dilation` whatever `pad` says (submodule.py:10-13); kept.
@@ -113,6 +118,38 @@ class feature_extraction(nn.Module):
         layers += [block(self.inplanes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
+    @staticmethod
+    def _bilinear_matrix(n_in, n_out, align_corners, device):
+        """(n_out, n_in) interpolation matrix of F.interpolate(mode="bilinear") along one axis."""
+        i = torch.arange(n_out, dtype=torch.float32, device=device)
+        if align_corners:
+            src = i * ((n_in - 1) / (n_out - 1)) if n_out > 1 else torch.zeros_like(i)
+        else:
+            src = ((i + 0.5) * (n_in / n_out) - 0.5).clamp_min(0.0)
+        i0 = src.floor().long().clamp_max(n_in - 1)
+        i1 = (i0 + 1).clamp_max(n_in - 1)
+        w1 = src - i0.to(src.dtype)
+        m = torch.zeros((n_out, n_in), dtype=torch.float32, device=device)
+        m.scatter_add_(1, i0[:, None], (1.0 - w1)[:, None])
+        m.scatter_add_(1, i1[:, None], w1[:, None])
+        return m
+
+    def _upsample(self, y, size):
+        """The branches' bilinear upsampling (submodule.py:118-128).  Under autograd on the GPU it is
+        two small matrix products Ry @ y @ Rx^T (bilinear interpolation is separable and linear), so
+        that its backward is two matrix products as well: torch's upsample_bilinear2d_backward
+        scatters with atomics and took 0.30 ms per branch and side, 2.4 ms of a 27 ms training step
+        (profiles/r02_train_kernel_stats.csv)."""
+        if not (y.is_cuda and torch.is_grad_enabled() and _SPP_MATMUL):
+            return F.interpolate(y, size=size, mode="bilinear", align_corners=self.align_corners)
+        key = (y.shape[2], y.shape[3], size[0], size[1], self.align_corners, y.device)
+        cache = self.__dict__.setdefault("_up_cache", {})
+        if key not in cache:
+            cache[key] = (self._bilinear_matrix(y.shape[2], size[0], self.align_corners, y.device),
+                          self._bilinear_matrix(y.shape[3], size[1], self.align_corners, y.device).t().contiguous())
+        ry, rxt = cache[key]
+        return torch.matmul(ry, torch.matmul(y.contiguous(), rxt))
+
     def _spp_stock(self, raw, skip):
         """The reference's SPP head with stock torch ops (training, autograd, CPU)."""
         size = skip.shape[2:]
@@ -124,7 +161,7 @@ class feature_extraction(nn.Module):
             pooled = F.avg_pool2d(pooled, 8 if i == 4 else 2)
             branch = getattr(self, "branch%d" % i)
             y = branch[1](pooled, relu=True)          # convbn + ReLU ([0] is the AvgPool2d)
-            pyramid.append(F.interpolate(y, size=size, mode="bilinear", align_corners=self.align_corners))
+            pyramid.append(self._upsample(y, size))
         return torch.cat([raw, skip] + pyramid, dim=1)
 
     def _spp_params(self):
@@ -167,6 +204,8 @@ class feature_extraction(nn.Module):
         else:
             if fast:
                 x = stage_image_nhwc16(x)                  # NHWC, 3 -> 16 staged channels
+            elif _TRAIN_NHWC and x.is_cuda:
+                x = x.contiguous(memory_format=torch.channels_last)
             for i in (0, 2, 4):
                 x = self.firstconv[i](x, relu=True)
             x = self.layer1(x)
