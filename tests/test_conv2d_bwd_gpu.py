@@ -155,3 +155,20 @@ def test_feature_extraction_train_step():
     med_stock = sorted(r[1] for r in rows)[len(rows) // 2]
     print("median %.2e (stock %.2e)" % (med, med_stock))
     assert med <= 3.0 * med_stock + 1e-4
+
+
+@pytest.mark.parametrize("align", [False, True])
+@pytest.mark.parametrize("hw,size", [((1, 2), (64, 128)), ((8, 16), (64, 128)), ((3, 5), (17, 33))])
+def test_spp_upsample_as_matrix_products(hw, size, align):
+    """The SPP branches' bilinear upsampling under autograd (two matrix products) equals
+    F.interpolate in value and gradient (models/psmnet/submodule.py:118-128)."""
+    from dsmnet_amd.models.psmnet.submodule import feature_extraction
+    net = feature_extraction(align_corners=align)
+    y = seeded(21, 2, 32, *hw).cuda().requires_grad_(True)
+    out = net._upsample(y, size)
+    ref = F.interpolate(y, size=size, mode="bilinear", align_corners=align)
+    assert out.shape == ref.shape and maxerr(out, ref) <= 2e-6
+    cot = seeded(22, *ref.shape).cuda()
+    (g,) = torch.autograd.grad(out, y, cot, retain_graph=True)
+    (gr,) = torch.autograd.grad(ref, y, cot)
+    assert maxerr(g, gr) <= 1e-4 * max(1.0, gr.abs().max().item())
