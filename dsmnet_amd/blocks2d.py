@@ -16,15 +16,21 @@ from . import costvolume as cv
 from . import blocks3d
 from .blocks3d import _versions
 
-# Training through the 2-D towers.  DSM_TRAIN_2D=fused (read by this host module) routes every tower
-# layer through costvolume.Conv2dFunction + the fused batch-statistics BN block; the default keeps the
-# stock torch layers: at PSMNet's training crop (256 x 512, maps of 64 x 128 pixels and smaller) the
-# fused path is correct (tests/test_conv2d_bwd_gpu.py) but SLOWER -- 38.0 vs 29.8 ms per replayed step
-# (DESIGN.md section 9): ~1,500 launches of 4-16 us each, tiles that fill a quarter of the CUs, and a
-# weight-gradient kernel that spends its time in atomics at these sizes.
-_TRAIN_2D_MODE = __import__("os").environ.get("DSM_TRAIN_2D", "stock")
-_FUSED_TRAIN_2D = _TRAIN_2D_MODE in ("fused", "conv")
-_FUSED_TRAIN_2D_BN = _TRAIN_2D_MODE == "fused"      # "conv": own convolutions, stock BatchNorm2d
+# Training through the 2-D towers (DSM_TRAIN_2D, read by this host module):
+#   auto  (default) a layer runs on costvolume.Conv2dFunction (forward, backward-data and weight
+#         gradient on the MFMA kernels) when its output has at least _TRAIN_2D_MIN_PIXELS pixels, on
+#         the stock torch layer otherwise; BatchNorm2d stays stock;
+#   conv  every eligible layer on Conv2dFunction, stock BatchNorm2d;
+#   fused the same plus the fused batch-statistics BN + skip + ReLU block (csrc/bn3d.hip);
+#   stock the stock torch layers only.
+# Measured (one replayed PSMNet step): at BASELINE config #5's shape (540 x 960,
+# 4 pairs: 1/4-resolution maps of 135 x 240 x 4) conv 177 / fused 179 / stock 192 ms; at the 256 x 512
+# crop (maps of 64 x 128 and smaller) stock 27.0 / conv 30.0 / fused 32.1 ms -- there the kernels
+# launch 16-64 workgroups and the per-step weight re-packing dominates.
+_TRAIN_2D_MODE = __import__("os").environ.get("DSM_TRAIN_2D", "auto")
+_FUSED_TRAIN_2D = _TRAIN_2D_MODE in ("auto", "fused", "conv")
+_FUSED_TRAIN_2D_BN = _TRAIN_2D_MODE == "fused"
+_TRAIN_2D_MIN_PIXELS = 65536 if _TRAIN_2D_MODE == "auto" else 0
 
 
 def s3in_ok(conv):
@@ -123,6 +129,8 @@ def train_ok(conv, x):
     if k[0] != k[1] or s[0] != s[1] or d[0] != d[1] or p[0] != p[1] or conv.groups != 1:
         return False
     if conv.bias is not None or conv.padding_mode != "zeros" or p[0] != d[0] * (k[0] // 2):
+        return False
+    if x.shape[0] * ((x.shape[2] - 1) // s[0] + 1) * ((x.shape[3] - 1) // s[0] + 1) < _TRAIN_2D_MIN_PIXELS:
         return False
     return x.shape[1] == conv.in_channels and cv.conv2d_variant(conv.out_channels, s[0], k[0], d[0])
 

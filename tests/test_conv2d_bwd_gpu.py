@@ -26,12 +26,12 @@ def cv(hip_lib):
 
 @pytest.fixture(autouse=True)
 def fused_towers():
-    """The fused tower path is opt-in (DSM_TRAIN_2D=fused): switch it on for these tests."""
+    """These tests run every layer on the own-kernel tower path (DSM_TRAIN_2D=fused), whatever its size."""
     from dsmnet_amd import blocks2d
-    old = blocks2d._FUSED_TRAIN_2D
-    blocks2d._FUSED_TRAIN_2D = True
+    old = (blocks2d._FUSED_TRAIN_2D, blocks2d._FUSED_TRAIN_2D_BN, blocks2d._TRAIN_2D_MIN_PIXELS)
+    blocks2d._FUSED_TRAIN_2D, blocks2d._FUSED_TRAIN_2D_BN, blocks2d._TRAIN_2D_MIN_PIXELS = True, True, 0
     yield
-    blocks2d._FUSED_TRAIN_2D = old
+    blocks2d._FUSED_TRAIN_2D, blocks2d._FUSED_TRAIN_2D_BN, blocks2d._TRAIN_2D_MIN_PIXELS = old
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,dil,shape", [
