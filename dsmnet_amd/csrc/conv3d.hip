@@ -1077,7 +1077,9 @@ int run_deconv_bf16x3(ConvParams p, hipStream_t s) {
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
   const size_t lds = (size_t)2 * 6 * 32 * 208 + 2 * 32 * NT * sizeof(float);   // two images (79.9 KB) + scale / shift
-  return launch_tiles(deconv_bf16x3_kernel<NT>, p, lds, s, 256);
+  // NT = 1 fits two workgroups per CU (198 registers, 2 x 80 KB of LDS): the second one computes while
+  // the first one's four-class epilogue (fp32 + S3 stores, skip read) drains
+  return launch_tiles(deconv_bf16x3_kernel<NT>, p, lds, s, NT == 1 ? 256 * DSM_DECONV_WGS : 256);
 }
 
 // Section 2 of a packed weight buffer (the pre-split bf16 planes), present for the shapes the

@@ -414,8 +414,11 @@ __host__ __device__ constexpr int dc_tap9(int j) {           // ky * 3 + kx of p
   return ky * 3 + kx;
 }
 
+#ifndef DSM_DECONV_WGS
+#define DSM_DECONV_WGS 2
+#endif
 template <int NT>
-__global__ __launch_bounds__(NTHREADS, 1) void deconv_bf16x3_kernel(ConvParams p) {
+__global__ __launch_bounds__(NTHREADS, NT == 1 ? DSM_DECONV_WGS : 1) void deconv_bf16x3_kernel(ConvParams p) {
   constexpr int TY = 4, IY = TY + 1, IX = 33, CK = 32;
   constexpr int NVOX = IY * IX;                 // 165
   constexpr int NE = NVOX * 8;                  // 1320 staged 16-B fp32 quads per chunk
