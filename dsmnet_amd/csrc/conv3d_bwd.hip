@@ -373,6 +373,37 @@ __global__ __launch_bounds__(NT_, 1) void wgrad_bf16x3_kernel(WgradParams p) {
     }
     cur = nxt;
   }
+  if constexpr (KZ == 1) {
+    // every wave holds partial sums of all nine taps: fold the four waves through LDS (the tiles are
+    // dead now), four taps per round, so that each (tap, c, g) leaves as ONE atomic per workgroup
+    float* const fold = reinterpret_cast<float*>(wl);          // [wave][4 taps][16][64]
+    static_assert(4 * 4 * 16 * 64 * 4 <= G::LDS, "fold buffer");
+    sfor<0, 3>([&](auto rc) {
+      constexpr int rnd = decltype(rc)::value;
+      __syncthreads();
+      sfor<0, 4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value, a = 4 * rnd + j;
+        if constexpr (a < NTAP) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) fold[((wave * 4 + j) * 16 + i) * 64 + lane] = acc[a][i];
+        }
+      });
+      __syncthreads();
+      const int tap = 4 * rnd + wave;
+      if (tap < NTAP) {
+        float* dst = p.ws + (((long)pair * NTAP + tap) * 32) * 32 + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) v += fold[((w * 4 + wave) * 16 + i) * 64 + lane];
+          const int c = (i & 3) + 8 * (i >> 2) + 4 * h;
+          atomicAdd(dst + c * 32, v);
+        }
+      }
+    });
+    return;
+  }
   // flush: ws[pair][tap][c][g] += acc  (row = c, column = g on the lanes)
   sfor<0, NACC>([&](auto ac) {
     constexpr int a = decltype(ac)::value;
