@@ -869,7 +869,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_zslide_kernel(
   const bool live = yo < p.Ho && xo < p.Wo;
   const float sc = p.scale ? p.scale[0] : 1.f, sh = p.shift ? p.shift[0] : 0.f;
 
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f;                    // outputs pz-1, pz, pz+1
+  typedef float f32x2p __attribute__((ext_vector_type(2)));
+  f32x2p a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};   // outputs pz-1, pz, pz+1 (even | odd channels)
   prefetch(max(z0 - 1, 0));
   for (int pz = z0 - 1; pz <= z1; ++pz) {
     if (pz >= 0 && pz < p.Di) {                          // planes outside the volume are zero
@@ -894,24 +895,26 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv3d_cout1_zslide_kernel(
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) {
+            // two channels per instruction (v_pk_fma_f32): even / odd channel sums, folded at the store
             const f32x4 a = rd[(dy * IX + dx) * PITCH + q];
             const f32x4 w0 = wv[0][dx], w1 = wv[1][dx], w2 = wv[2][dx];
-            a2 = fmaf(a.x, w0.x, a2); a2 = fmaf(a.y, w0.y, a2); a2 = fmaf(a.z, w0.z, a2); a2 = fmaf(a.w, w0.w, a2);
-            a1 = fmaf(a.x, w1.x, a1); a1 = fmaf(a.y, w1.y, a1); a1 = fmaf(a.z, w1.z, a1); a1 = fmaf(a.w, w1.w, a1);
-            a0 = fmaf(a.x, w2.x, a0); a0 = fmaf(a.y, w2.y, a0); a0 = fmaf(a.z, w2.z, a0); a0 = fmaf(a.w, w2.w, a0);
+            const f32x2p alo = {a.x, a.y}, ahi = {a.z, a.w};
+            a2 = __builtin_elementwise_fma(alo, f32x2p{w0.x, w0.y}, a2); a2 = __builtin_elementwise_fma(ahi, f32x2p{w0.z, w0.w}, a2);
+            a1 = __builtin_elementwise_fma(alo, f32x2p{w1.x, w1.y}, a1); a1 = __builtin_elementwise_fma(ahi, f32x2p{w1.z, w1.w}, a1);
+            a0 = __builtin_elementwise_fma(alo, f32x2p{w2.x, w2.y}, a0); a0 = __builtin_elementwise_fma(ahi, f32x2p{w2.z, w2.w}, a0);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
     }
     const int zo = pz - 1;                               // a0 has seen its three planes
     if (zo >= z0 && zo < z1 && live) {
-      float v = a0 * sc + sh;
+      float v = (a0.x + a0.y) * sc + sh;
       if (p.relu == 2) v = fmaxf(v, 0.f);
       if (p.res) v += p.res[(((long)b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo];
       if (p.relu == 1) v = fmaxf(v, 0.f);
       p.y[(((long)b * p.Do + zo) * p.Ho + yo) * p.Wo + xo] = v;
     }
-    a0 = a1; a1 = a2; a2 = 0.f;
+    a0 = a1; a1 = a2; a2 = f32x2p{0.f, 0.f};
   }
 }
 

@@ -1,4 +1,4 @@
-"""Same-process A/B of two builds of the library on the transposed 3-D convolution (interleaved rounds;
+"""Same-process A/B of two builds of the library on the transposed 3-D convolution or (--cout 1) the heads' 32 -> 1 convolution (interleaved rounds;
 MI355X devices differ by up to 10 % on MFMA-dense kernels, so builds are only ever ranked inside one
 run).    python3 scripts/ab_deconv.py libA.so libB.so [--cout 32|64] [--out f32|both] [--res]"""
 import argparse
@@ -21,12 +21,13 @@ _lib.load()
 dev = "cuda"
 torch.manual_seed(0)
 CL = torch.channels_last_3d
-cin = 64
-din = (24, 48, 160) if args.cout == 32 else (12, 24, 80)
-dout = tuple(2 * d for d in din)
+head = args.cout == 1                        # --cout 1: the classifier heads' 32 -> 1 convolution instead
+cin = 32 if head else 64
+din = (48, 96, 320) if head else ((24, 48, 160) if args.cout == 32 else (12, 24, 80))
+dout = din if head else tuple(2 * d for d in din)
 x = torch.randn(1, cin, *din, device=dev).contiguous(memory_format=CL)
-w = torch.randn(cin, args.cout, 3, 3, 3, device=dev) * 0.05
-packed = cv.pack_conv3d_weight(w, True)
+w = torch.randn(1, cin, 3, 3, 3, device=dev) * 0.05 if head else torch.randn(cin, args.cout, 3, 3, 3, device=dev) * 0.05
+packed = cv.pack_conv3d_weight(w, not head)
 res = torch.randn(1, args.cout, *dout, device=dev).contiguous(memory_format=CL) if args.res else None
 y = torch.empty(1, args.cout, *dout, device=dev).contiguous(memory_format=CL)
 ys3 = torch.empty(y.numel() * 6, device=dev, dtype=torch.uint8)
@@ -39,7 +40,9 @@ a.B, a.Cin, a.Cout = 1, cin, args.cout
 a.Di, a.Hi, a.Wi = din
 a.Do, a.Ho, a.Wo = dout
 a.Dr, a.Hr, a.Wr = dout
-a.stride, a.transposed, a.relu = 2, 1, 1
+a.stride, a.transposed, a.relu = (1, 0, 0) if head else (2, 1, 1)
+if head:
+    a.y_s3 = None
 fns = []
 for path in args.libs:
     lib = ctypes.CDLL(path)
