@@ -163,24 +163,39 @@ __global__ __launch_bounds__(256) void soft_argmin_up4_kernel(SaParams p) {
     // exp(m_old - m_new) whenever a larger P arrives (one extra v_exp per plane, 5 instead of
     // 4 + a second sampling pass).  Mathematically the softmax is shift-invariant; numerically
     // each rescale costs one rounding of l and sum, and it happens O(log Dc) times on average.
-    float Pm = sg * plane_at(base, ps, max(k_lo - 1, 0), st);
-    float Pc = sg * plane_at(base, ps, k_lo, st);
-    float m = fmaxf(Pm, Pc), l = 0.f, sum = 0.f;
+    // The loop works in base-2 units (samples pre-multiplied by log2 e: v_exp_f32 is 2^x) and on
+    // PAIRS of fine bins -- (4k, 4k+1) and (4k+2, 4k+3) -- with packed fp32 instructions
+    // (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): ~27 vector operations + 5 v_exp per coarse
+    // plane instead of ~45 + 5 (the kernel is VALU-bound).  l and sum are kept as (even | odd) bin
+    // pairs and folded at the end.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    const float sg2 = sg * LOG2E;
+    float Pm = sg2 * plane_at(base, ps, max(k_lo - 1, 0), st);
+    float Pc = sg2 * plane_at(base, ps, k_lo, st);
+    float m = fmaxf(Pm, Pc);
+    f2 l2 = {0.f, 0.f}, s2 = {0.f, 0.f};
+    f2 d01 = {(float)(4 * k_lo), (float)(4 * k_lo + 1)}, d23 = {(float)(4 * k_lo + 2), (float)(4 * k_lo + 3)};
+    const f2 ca = {0.375f, 0.125f}, cb = {0.625f, 0.875f}, four = {4.f, 4.f};
     for (int k = k_lo; k < k_hi; ++k) {
-      const float Pn = sg * plane_at(base, ps, min(k + 1, p.Dc - 1), st);
+      const float Pn = sg2 * plane_at(base, ps, min(k + 1, p.Dc - 1), st);
       const float mn = fmaxf(m, Pn);
-      const float rs = __expf(m - mn);                     // 1 when the maximum stands
-      l *= rs; sum *= rs; m = mn;
-      const float d0 = (float)(4 * k);
-      const float e0 = __expf(0.375f * Pm + 0.625f * Pc - m);
-      const float e1 = __expf(0.125f * Pm + 0.875f * Pc - m);
-      const float e2 = __expf(0.875f * Pc + 0.125f * Pn - m);
-      const float e3 = __expf(0.625f * Pc + 0.375f * Pn - m);
-      l += (e0 + e1) + (e2 + e3);
-      sum = fmaf(d0, e0, sum); sum = fmaf(d0 + 1.f, e1, sum);
-      sum = fmaf(d0 + 2.f, e2, sum); sum = fmaf(d0 + 3.f, e3, sum);
+      const float rs = __builtin_amdgcn_exp2f(m - mn);     // 1 when the maximum stands
+      l2 *= f2{rs, rs}; s2 *= f2{rs, rs}; m = mn;
+      const f2 nm = {-m, -m};
+      // (v0, v1) = (.375, .125) Pm + (.625, .875) Pc - m;  (v3, v2) = (.375, .125) Pn + (.625, .875) Pc - m
+      const f2 v01 = __builtin_elementwise_fma(ca, f2{Pm, Pm}, __builtin_elementwise_fma(cb, f2{Pc, Pc}, nm));
+      const f2 v32 = __builtin_elementwise_fma(ca, f2{Pn, Pn}, __builtin_elementwise_fma(cb, f2{Pc, Pc}, nm));
+      const f2 e01 = {__builtin_amdgcn_exp2f(v01.x), __builtin_amdgcn_exp2f(v01.y)};
+      const f2 e23 = {__builtin_amdgcn_exp2f(v32.y), __builtin_amdgcn_exp2f(v32.x)};
+      l2 += e01; l2 += e23;
+      s2 = __builtin_elementwise_fma(d01, e01, s2);
+      s2 = __builtin_elementwise_fma(d23, e23, s2);
+      d01 += four; d23 += four;
       Pm = Pc; Pc = Pn;
     }
+    float l = l2.x + l2.y, sum = s2.x + s2.y;
+    m *= LN2;                                              // back to natural units (stats, merge)
     // Guard: the running maximum of the P's can exceed every FINE value by more than the range
     // of expf (an isolated peak of height h leaves 0.875 h as the largest fine value): all terms
     // then underflow.  Such a segment (l tiny or zero) is redone with the exact maximum of its
