@@ -199,9 +199,4 @@ class ConvBN2d(nn.Sequential):
 def stage_image_nhwc16(img):
     """(B,3,H,W) image -> (B,16,H,W) channels_last with zero channels 3..15, the 16-channel
     granularity the MFMA kernel stages (the first convolution's weights are zero-padded to match)."""
-    B, C, H, W = img.shape
-    out = torch.empty((B, 16, H, W), device=img.device, dtype=img.dtype,
-                      memory_format=torch.channels_last)
-    out[:, :C] = img
-    out[:, C:] = 0
-    return out
+    return cv.stage_images_nhwc16(img, None)

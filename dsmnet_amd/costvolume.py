@@ -943,6 +943,25 @@ def bn_add_relu3d(y, gamma, beta, residual, running_mean, running_var, relu, mom
                                      float(momentum), float(eps))
 
 
+def stage_images_nhwc16(left, right=None):
+    """The towers' input staging in one launch: (B,C,H,W) image(s), C <= 16, -> (B or 2B, 16, H, W)
+    channels_last with zero channels C..15; with ``right`` the two views share the batch
+    (left first), as PSMNet's eval forward feeds them."""
+    _require_device("stage_images_nhwc16", left, right)
+    left = left.contiguous()
+    B, C, H, W = left.shape
+    if right is not None:
+        if tuple(right.shape) != tuple(left.shape):
+            raise ValueError("stage_images_nhwc16: the two views differ in shape")
+        right = right.contiguous()
+    out = torch.empty(((1 if right is None else 2) * B, 16, H, W), device=left.device,
+                      dtype=torch.float32, memory_format=_CL2D)
+    with torch.cuda.device(left.device):
+        rc = _lib.load().dsm_stage_images_nhwc16(_p(left), _p(right), _p(out), B, C, H, W, _stream())
+    _lib.check(rc, "dsm_stage_images_nhwc16")
+    return out
+
+
 # ----------------------------------------------------------------------------
 # the 2-D towers in training: convolution with explicit gradients, batch-statistics BN
 # ----------------------------------------------------------------------------

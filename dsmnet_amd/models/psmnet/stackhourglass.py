@@ -104,7 +104,11 @@ class PSMNet(nn.Module):
         if self.training:
             return self.feature_extraction(left), self.feature_extraction(right)
         # eval: BN uses running statistics, so both views can share one batch
-        both = self.feature_extraction(torch.cat([left, right], dim=0))
+        if left.is_cuda and not torch.is_grad_enabled() and left.shape[1] <= 16:
+            # concatenation + NHWC staging (3 -> 16 channels) in one launch
+            both = self.feature_extraction(cv.stage_images_nhwc16(left, right), staged=True)
+        else:
+            both = self.feature_extraction(torch.cat([left, right], dim=0))
         return both[: left.shape[0]], both[left.shape[0]:]
 
     def _s3_path(self):

@@ -182,10 +182,10 @@ class feature_extraction(nn.Module):
             self._spp_key = key
         return self._spp_cache
 
-    def _trunk_s3(self, x):
+    def _trunk_s3(self, x, staged=False):
         """firstconv .. layer4 in eval mode with S3 hand-over between the bf16x3 convolutions.
         Returns (raw, skip) as fp32 maps."""
-        x = self.firstconv[0](stage_image_nhwc16(x), relu=True)    # 3 -> 32, stride 2: fp32-input MFMA
+        x = self.firstconv[0](x if staged else stage_image_nhwc16(x), relu=True)    # 3 -> 32, stride 2: fp32-input MFMA
         x_s = self.firstconv[2](x, relu=True, out="s3")
         x_f, x_s = self.firstconv[4](x_s, relu=True, out="both")
         blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
@@ -197,12 +197,16 @@ class feature_extraction(nn.Module):
                 raw = x_f
         return raw, x_f
 
-    def forward(self, x):
+    def forward(self, x, staged=False):
+        """``staged``: ``x`` is already the (B,16,H,W) NHWC staging of the image(s)
+        (``costvolume.stage_images_nhwc16``; eval fast path only)."""
         fast = x.is_cuda and not self.training and not torch.is_grad_enabled()
+        if staged and not fast:
+            raise RuntimeError("feature_extraction: staged input exists on the eval fast path only")
         if fast and cv.get_option("s3") and cv.get_option("s3in") and cv.get_option_bf16x3():
-            raw, skip = self._trunk_s3(x)
+            raw, skip = self._trunk_s3(x, staged)
         else:
-            if fast:
+            if fast and not staged:
                 x = stage_image_nhwc16(x)                  # NHWC, 3 -> 16 staged channels
             elif _TRAIN_NHWC and x.is_cuda:
                 x = x.contiguous(memory_format=torch.channels_last)

@@ -377,6 +377,13 @@ int dsm_decoder_cat(const void* up, const void* bias, const void* pr, const void
                     int B, int Cu, int Cp, int Cs, int Hu, int Wu, int Hp, int Wp, int Hs, int Ws,
                     int relu, dsm_stream_t stream);
 
+/* (ABI v5) Image staging of the 2-D towers (models/psmnet/stackhourglass.py:118-121 feeds the two
+ * views through feature_extraction one after the other; in eval mode they share one batch):
+ * left, right (B,C,H,W) NCHW fp32, C <= 16 -> out (2B,16,H,W) in NHWC memory, channels C..15 zero.
+ * right = NULL stages one view (B images). */
+int dsm_stage_images_nhwc16(const void* left, const void* right, void* out, int B, int C, int H, int W,
+                            dsm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -246,3 +246,16 @@ def test_gcnet_lr_left_output_equals_gcnet(hip_lib, golden_e2e):
     h, w = imL.shape[-2:]
     assert maxerr(oL, wantL[:, :, :h, :w]) <= 1e-3
     assert maxerr(oR, wantR[:, :, :h, :w]) <= 1e-3
+
+
+@pytest.mark.parametrize("shape,pair", [((2, 3, 17, 37), True), ((1, 3, 16, 40), False), ((1, 16, 5, 9), True)])
+def test_stage_images_nhwc16(cv, shape, pair):
+    """The towers' one-launch input staging == torch.cat of the views + zero channels, in NHWC memory
+    (bit-identical: a copy)."""
+    left, right = dev(seeded(51, *shape)), (dev(seeded(52, *shape)) if pair else None)
+    out = cv.stage_images_nhwc16(left, right)
+    ref = left if right is None else torch.cat([left, right], 0)
+    assert out.shape == (ref.shape[0], 16) + tuple(shape[2:])
+    assert out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out[:, : shape[1]], ref)
+    assert float(out[:, shape[1]:].abs().max()) == 0.0 if shape[1] < 16 else True
