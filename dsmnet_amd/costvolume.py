@@ -448,7 +448,7 @@ import os as _os
 # DSM_CONV_PRECISION=fp32|bf16x3 so that scripts and the parity tests can switch whole runs
 _OPTIONS = {"s3": True, "fuse_volume": True, "s3in": False,
             "conv_fp32": _os.environ.get("DSM_CONV_PRECISION", "").startswith("f"),
-            "conv_flags": 0, "s3_tiling": 0}
+            "conv_flags": 0, "s3_tiling": 0, "overlap_heads": False}
 
 
 def set_option(name, value):
@@ -462,7 +462,10 @@ def set_option(name, value):
     split already rides in the shadow of the 32-cycle 32x32x16 MFMAs, while an S3 input costs 50 %
     more staged bytes and its producer an epilogue split.
     ``s3_tiling`` -- dsm_conv3d_s3_args.tiling of every S3 convolution launch (0 = the library's
-    default, 1 = 8 x 32 tile / one workgroup per CU, 2 = 4 x 32 tile / two per CU)."""
+    default, 1 = 8 x 32 tile / one workgroup per CU, 2 = 4 x 32 tile / two per CU);
+    ``overlap_heads`` -- PSMNet's eval forward runs classif1/classif2 and their soft-argmin heads on a
+    second HIP stream beside the next hourglass (fork / join with events; a hipGraph captures both
+    branches)."""
     if name not in _OPTIONS:
         raise KeyError(name)
     old = _OPTIONS[name]

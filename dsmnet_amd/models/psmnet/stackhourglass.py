@@ -149,6 +149,34 @@ class PSMNet(nn.Module):
         cost3 = self.classif3(o3_s, residual=cost2)
         return cost1, cost2, cost3
 
+    def _heads_beside_the_trunk(self, cost, size):
+        """The S3 eval dataflow of ``regularise`` + the three heads with classif1 / classif2 and their
+        soft-argmin on a second stream: they depend on out1 / out2 only, the next hourglass does not
+        depend on them (stackhourglass.py:146-166), and several of its kernels leave CUs idle (the
+        12 x 24 x 80 layers launch 108-216 workgroups).  Fork / join with events; under
+        ``torch.cuda.graph`` both branches are captured."""
+        main = torch.cuda.current_stream()
+        side = self.__dict__.get("_side_stream")
+        if side is None or side.device != cost.device:
+            side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=cost.device)
+        sa = lambda c: cv.soft_argmin(c, size, align_corners=self.align_corners)
+        c0a_f, c0a_s = self.dres0(cost, out="both")
+        cost0 = self.dres1(c0a_s, residual=c0a_f)
+        (o1_f, o1_s), pre1, post1 = self.dres2(cost0, None, None, skip=cost0, out_format="both")
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            cost1 = self.classif1(o1_s)
+            pred1 = sa(cost1)
+        (o2_f, o2_s), pre2, post2 = self.dres3(o1_f, pre1, post1, skip=cost0, out_format="both")
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            cost2 = self.classif2(o2_s, residual=cost1)
+            pred2 = sa(cost2)
+        o3_s, pre3, post3 = self.dres4(o2_f, pre1, post2, skip=cost0, out_format="s3")
+        main.wait_stream(side)
+        pred3 = sa(self.classif3(o3_s, residual=cost2))
+        return pred1, pred2, pred3
+
     def forward(self, left, right, mode="train"):
         refimg_fea, targetimg_fea = self.features(left, right)
         if self._s3_path() and cv.get_option("fuse_volume"):
@@ -158,8 +186,11 @@ class PSMNet(nn.Module):
                                        materialise=False)
         else:
             cost = cv.concat_volume(refimg_fea, targetimg_fea, self.maxdisp // 4, mask_left=True)
-        cost1, cost2, cost3 = self.regularise(cost)
         size = (self.maxdisp, left.shape[2], left.shape[3])
+        if self._s3_path() and cv.get_option("overlap_heads") and not cv.get_option("s3in"):
+            pred1, pred2, pred3 = self._heads_beside_the_trunk(cost, size)
+            return [0, 0, 0], [pred3, pred2, pred1]
+        cost1, cost2, cost3 = self.regularise(cost)
         pred1 = cv.soft_argmin(cost1, size, align_corners=self.align_corners)
         pred2 = cv.soft_argmin(cost2, size, align_corners=self.align_corners)
         pred3 = cv.soft_argmin(cost3, size, align_corners=self.align_corners)

@@ -18,28 +18,41 @@ l, r = torch.rand(1, 3, H, W, generator=g).to(dev), torch.rand(1, 3, H, W, gener
 calibrate.calibrate_batchnorm(m, l, r)
 calibrate.calibrate_psmnet_heads(m, l, r)
 m.eval()
-# (s3, fuse_volume, s3_tiling); s3in stays off
-configs = {"s3+fuse": (True, True, 0), "s3": (True, False, 0), "r01": (False, False, 0),
-           "tile8x32": (True, True, 1), "tile4x32": (True, True, 2)}
+# (s3, fuse_volume, s3_tiling, overlap_heads); s3in stays off
+configs = {"s3+fuse": (True, True, 0, False), "s3": (True, False, 0, False), "r01": (False, False, 0, False),
+           "tile8x32": (True, True, 1, False), "tile4x32": (True, True, 2, False),
+           "overlap": (True, True, 0, True)}
+GRAPH = "--graph" in sys.argv                      # time hipGraph replays instead of eager launches
+sys.argv = [a for a in sys.argv if a != "--graph"]
 if len(sys.argv) > 1:
     configs = {k: v for k, v in configs.items() if k in sys.argv[1:]}
 res = {k: [] for k in configs}
 stages = {}
+graphs = {}
+from dsmnet_amd.graphs import GraphedForward
 with torch.no_grad():
     for rnd in range(6):
-        for name, (s3, fuse, tiling) in configs.items():
+        for name, (s3, fuse, tiling, overlap) in configs.items():
             cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse), cv.set_option("s3_tiling", tiling)
+            cv.set_option("overlap_heads", overlap)
+            if GRAPH:
+                if name not in graphs:
+                    graphs[name] = GraphedForward(m, l, r)
+                run = graphs[name].replay
+            else:
+                run = lambda: m(l, r)
             for _ in range(2):
-                m(l, r)
+                run()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(10):
-                m(l, r)
+                run()
             torch.cuda.synchronize()
             if rnd:
                 res[name].append((time.perf_counter() - t0) / 10 * 1e3)
-    for name, (s3, fuse, tiling) in configs.items():
+    for name, (s3, fuse, tiling, overlap) in configs.items():
         cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse), cv.set_option("s3_tiling", tiling)
+        cv.set_option("overlap_heads", False)
         t = cv.LaunchTimer()
         cv.set_timer(t)
         for _ in range(5):
@@ -49,7 +62,7 @@ with torch.no_grad():
         stages[name] = {k: (v["ms"] / 5, v["launches"] / 5) for k, v in t.summary().items()}
 for name, t in res.items():
     t = sorted(t)
-    print("%-10s eager forward: median %.3f ms  min %.3f ms" % (name, t[len(t) // 2], t[0]))
+    print("%-10s %s forward: median %.3f ms  min %.3f ms" % (name, "replayed" if GRAPH else "eager", t[len(t) // 2], t[0]))
 names = sorted({k for s in stages.values() for k in s})
 for k in names:
     print("%-62s" % k + "  ".join("%s %6.3f ms (%2d)" % (c, stages[c].get(k, (0, 0))[0], stages[c].get(k, (0, 0))[1]) for c in stages))
