@@ -1066,11 +1066,13 @@ int run_conv_bf16x3(ConvParams p, hipStream_t s) {
   const long nt = (long)p.B * p.Do * p.nty * p.ntx;
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
-  // two images, one workgroup per CU
-  const size_t lds = ((S == 1 && !S3IN) ? (size_t)2 * NPF * 64 * 112
+  // two images; one workgroup per CU, or two where conv_bf16x3_two_per_cu says both fit
+  constexpr bool TWO = conv_bf16x3_two_per_cu<NT, TM, S, S3IN>();
+  const size_t lds = ((S == 1 && !S3IN) ? (size_t)2 * (TWO ? (IY * IX + 4) * 112 : NPF * 64 * 112)
                                        : (size_t)2 * (IY * (S == 1 ? IX : 66) + 4) * 112) +
                      2 * 32 * NT * sizeof(float);                    // + scale / shift
-  return launch_tiles(conv_bf16x3_kernel<NT, TM, KZ, DIL, S, S3IN>, p, lds, s, 256);
+  static_assert(!TWO || 2 * (2 * (IY * IX + 4) * 112 + 2 * 32 * NT * 4) <= 160 * 1024, "two workgroups per CU");
+  return launch_tiles(conv_bf16x3_kernel<NT, TM, KZ, DIL, S, S3IN>, p, lds, s, TWO ? 512 : 256);
 }
 
 template <int NT>

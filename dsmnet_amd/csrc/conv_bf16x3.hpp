@@ -87,8 +87,16 @@ __device__ __forceinline__ Affine load_affine_lds(const float* aff, int cout, in
 // 2 (ck & 1), 2 (ck & 1) + 1 of channel group ck / 2: k-slot j of lane half h is channel
 // 32 (ck / 2) + 16 (j / 4) + 4 (2 (ck & 1) + h) + (j & 3); the weights are packed in that order
 // (dsm_conv_pack_weights_s3in).
+// Variants whose registers (<= 236 at a forced occupancy of 2, no scratch) and LDS (two exact-size
+// images) let TWO workgroups share a CU: the second one computes while the first one's prologue /
+// epilogue runs -- what the transposed kernel gained 7-12 % from.  (The 16-row and 128-channel
+// variants need one CU's LDS or registers for themselves.)
+template <int NT, int TM, int S, bool S3IN>
+constexpr bool conv_bf16x3_two_per_cu() { return S == 1 && !S3IN && NT <= 2 && TM <= 2; }
+
 template <int NT, int TM, int KZ, int DIL, int S = 1, bool S3IN = false>
-__global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) {
+__global__ __launch_bounds__(NTHREADS, (conv_bf16x3_two_per_cu<NT, TM, S, S3IN>() ? 2 : 1))
+void conv_bf16x3_kernel(ConvParams p) {
   static_assert(S == 1 || (S == 2 && DIL == 1 && KZ == 3), "stride 2: 3x3x3, no dilation");
   constexpr int TY = 4 * TM, NQ = S3IN ? 6 : 4, CK = 16;
   constexpr int IY = (TY - 1) * S + 2 * DIL + 1, IX = 31 * S + 2 * DIL + 1;
@@ -97,7 +105,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
   constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
   constexpr int PITCH = 112;                    // bytes per voxel in LDS: 3 planes x 32 B + 16 pad
   constexpr int RP = (S == 1) ? IX : 66;        // voxels per image row
-  constexpr int IMG = (S == 1 && !S3IN) ? NPF * 64 * PITCH : (IY * RP + 4) * PITCH;   // (fp32, S = 1: the tail quads land in padding)
+  constexpr bool TWO = conv_bf16x3_two_per_cu<NT, TM, S, S3IN>();
+  // fp32 input, S = 1: the last pass's tail quads land in padding behind the image -- or, where two
+  // workgroups share the CU, are not stored (exact-size image)
+  constexpr int IMG = (S == 1 && !S3IN) ? (TWO ? (NVOX + 4) * PITCH : NPF * 64 * PITCH) : (IY * RP + 4) * PITCH;
   constexpr int NITEM = 9;
   constexpr int NGROUP = NITEM * TM;            // (tap, row) groups of 6 NT MFMAs per chunk
   constexpr int AHEAD = 3;                      // weight ring: two items ahead (eight measured the same, twice)
@@ -242,8 +253,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_bf16x3_kernel(ConvParams p) 
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         u32x2 v; v.x = half_a[q]; v.y = pl[q];
-        if constexpr (S == 1) *reinterpret_cast<u32x2*>(img + wr_off + k * (64 * PITCH) + q * 32) = v;
-        else *reinterpret_cast<u32x2*>(img + wofs[k] + q * 32) = v;
+        if constexpr (S == 1) {
+          if (!TWO || k < NPF - 1 || tid < NE - (NPF - 1) * NTHREADS)
+            *reinterpret_cast<u32x2*>(img + wr_off + k * (64 * PITCH) + q * 32) = v;
+        } else {
+          *reinterpret_cast<u32x2*>(img + wofs[k] + q * 32) = v;
+        }
       }
     }
   };
