@@ -115,8 +115,10 @@ __device__ __forceinline__ Tap tap_at(int o, int in_size, int out_size) {
   return r;
 }
 
-// thread = (pixel, 16-B channel quad); 80 quads per pixel, consecutive threads -> consecutive
-// quads: 1280 contiguous bytes written per pixel
+// A workgroup takes 16 pixels at a time: thread = (pixel tid / 16, quad tid % 16 + 16 pass), five
+// passes over the pixel's 80 16-byte quads -- 256 contiguous bytes per pixel and pass, the pixel's
+// coordinates and bilinear taps computed once, 32-bit index arithmetic (the first form, one flat
+// 64-bit index per quad with a division by 80 and by W, H each, spent its time in integer division).
 __global__ __launch_bounds__(256) void spp_concat_kernel(const float* __restrict__ raw,
                                                          const float* __restrict__ skip,
                                                          const float* __restrict__ br,
@@ -124,28 +126,28 @@ __global__ __launch_bounds__(256) void spp_concat_kernel(const float* __restrict
                                                          int W, int h8, int w8) {
   constexpr int NQ = C_OUT / 4;
   const BranchGeo g = branch_geo(B, h8, w8);
-  const long n = (long)B * H * W * NQ;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % NQ);
-    const long pix = i / NQ;
-    f32x4 val;
-    if (q < C_RAW / 4) {
-      val = reinterpret_cast<const f32x4*>(raw + pix * C_RAW)[q];
-    } else if (q < (C_RAW + C_SKIP) / 4) {
-      val = reinterpret_cast<const f32x4*>(skip + pix * C_SKIP)[q - C_RAW / 4];
-    } else {
-      const int bi = (q - (C_RAW + C_SKIP) / 4) >> 3, cq = (q - (C_RAW + C_SKIP) / 4) & 7;
-      const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+  const int npix = B * H * W;                                    // < 2^31: checked by the host
+  const int lp = threadIdx.x >> 4, lq = threadIdx.x & 15;
+  for (int pix = blockIdx.x * 16 + lp; pix < npix; pix += gridDim.x * 16) {
+    const int x = pix % W, y = (pix / W) % H, b = pix / (W * H);
+    f32x4* dst = reinterpret_cast<f32x4*>(out) + (long)pix * NQ;
+    // passes 0 (raw: quads 0..15), 1..2 (skip: quads 16..47)
+    dst[lq] = reinterpret_cast<const f32x4*>(raw + (long)pix * C_RAW)[lq];
+    dst[16 + lq] = reinterpret_cast<const f32x4*>(skip + (long)pix * C_SKIP)[lq];
+    dst[32 + lq] = reinterpret_cast<const f32x4*>(skip + (long)pix * C_SKIP)[16 + lq];
+    // passes 3..4: quads 48..79 = four branches x 8 quads
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int bq = 16 * pass + lq, bi = bq >> 3, cq = bq & 7;
       const int hb = g.h[bi], wb = g.w[bi];
       const Tap ty = tap_at(y, hb, H), tx = tap_at(x, wb, W);
       const f32x4* m = reinterpret_cast<const f32x4*>(br + g.off[bi] + (long)b * hb * wb * C_BR) + cq;
-      const f32x4 v00 = m[((long)ty.i0 * wb + tx.i0) * (C_BR / 4)];
-      const f32x4 v01 = m[((long)ty.i0 * wb + tx.i1) * (C_BR / 4)];
-      const f32x4 v10 = m[((long)ty.i1 * wb + tx.i0) * (C_BR / 4)];
-      const f32x4 v11 = m[((long)ty.i1 * wb + tx.i1) * (C_BR / 4)];
-      val = ty.w0 * (tx.w0 * v00 + tx.w1 * v01) + ty.w1 * (tx.w0 * v10 + tx.w1 * v11);
+      const f32x4 v00 = m[(ty.i0 * wb + tx.i0) * (C_BR / 4)];
+      const f32x4 v01 = m[(ty.i0 * wb + tx.i1) * (C_BR / 4)];
+      const f32x4 v10 = m[(ty.i1 * wb + tx.i0) * (C_BR / 4)];
+      const f32x4 v11 = m[(ty.i1 * wb + tx.i1) * (C_BR / 4)];
+      dst[48 + bq] = ty.w0 * (tx.w0 * v00 + tx.w1 * v01) + ty.w1 * (tx.w0 * v10 + tx.w1 * v11);
     }
-    reinterpret_cast<f32x4*>(out)[i] = val;
   }
 }
 
@@ -190,8 +192,9 @@ extern "C" int dsm_spp_concat(const void* raw, const void* skip, const void* bra
   DSM_REQUIRE(B > 0 && H >= 64 && W >= 64, DSM_ERR_ARG);
   DSM_REQUIRE(dsm_aligned16(raw) && dsm_aligned16(skip) && dsm_aligned16(branches) &&
               dsm_aligned16(out), DSM_ERR_ALIGN);
-  const long n = (long)B * H * W * (C_OUT / 4);
-  const long blocks = n / 256 + 1 < 256 * 32 ? n / 256 + 1 : 256 * 32;   // grid-stride beyond 32 per CU
+  const long npix = (long)B * H * W;
+  DSM_REQUIRE(npix < 0x7fffffffL, DSM_ERR_UNSUPPORTED);
+  const long blocks = (npix + 15) / 16 < 256 * 32 ? (npix + 15) / 16 : 256 * 32;   // grid-stride beyond 32 per CU
   dsm_clear_stale_error();
   hipLaunchKernelGGL(spp_concat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      (const float*)raw, (const float*)skip, (const float*)branches, (float*)out,
