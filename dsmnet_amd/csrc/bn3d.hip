@@ -73,6 +73,16 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, const float
   if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(n > 1.0 ? var * n / (n - 1.0) : var);
 }
 
+// y, residual and output boxes coincide (no myadd_3d crop): every tensor shares one voxel index
+__device__ __forceinline__ bool same_boxes(const BnDims& d, bool with_res) {
+  return d.Do == d.Dy && d.Ho == d.Hy && d.Wo == d.Wy &&
+         (!with_res || (d.Dr == d.Dy && d.Hr == d.Hy && d.Wr == d.Wy));
+}
+// quad index of flat element i: a mask when C / 4 is a power of two (every layer of these networks)
+__device__ __forceinline__ int quad_of(long i, int nq) {
+  return (nq & (nq - 1)) == 0 ? (int)(i & (nq - 1)) : (int)(i % nq);
+}
+
 // out[b,z,y,x,:] = relu?( y*scale + shift (+ res) ) over the common corner; thread = (out voxel, quad)
 // relu: 0 none, 1 after the addition (PSMNet), 2 before it (GCNet)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ res,
@@ -82,20 +92,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   const long n = (long)d.B * d.Do * d.Ho * d.Wo * nq;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const int q = i % nq;
-  long v = i / nq;
-  const int x = v % d.Wo; v /= d.Wo;
-  const int yy = v % d.Ho; v /= d.Ho;
-  const int z = v % d.Do; const int b = v / d.Do;
-  const long vy = (((long)b * d.Dy + z) * d.Hy + yy) * d.Wy + x;
+  const int q = quad_of(i, nq);
+  long vy, vr;
+  if (same_boxes(d, res != nullptr)) {            // no crop: one linear index for y, res and out
+    vy = vr = i / nq;                              // (no coordinate decomposition: four 64-bit divisions per quad
+  } else {                                         //  made these passes VALU-bound instead of HBM-bound)
+    long v = i / nq;
+    const int x = v % d.Wo; v /= d.Wo;
+    const int yy = v % d.Ho; v /= d.Ho;
+    const int z = v % d.Do; const int b = v / d.Do;
+    vy = (((long)b * d.Dy + z) * d.Hy + yy) * d.Wy + x;
+    vr = (((long)b * d.Dr + z) * d.Hr + yy) * d.Wr + x;
+  }
   const f32x4 sc = *reinterpret_cast<const f32x4*>(aff + 4 * q);
   const f32x4 sh = *reinterpret_cast<const f32x4*>(aff + d.C + 4 * q);
   f32x4 t = *reinterpret_cast<const f32x4*>(y + vy * d.C + 4 * q) * sc + sh;
   if (relu == 2) t = relu4(t);
-  if (res) {
-    const long vr = (((long)b * d.Dr + z) * d.Hr + yy) * d.Wr + x;
-    t += *reinterpret_cast<const f32x4*>(res + vr * d.C + 4 * q);
-  }
+  if (res) t += *reinterpret_cast<const f32x4*>(res + vr * d.C + 4 * q);
   if (relu == 1) t = relu4(t);
   *reinterpret_cast<f32x4*>(out + i * 4) = t;
 }
@@ -114,12 +127,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const f32x4 sh = *reinterpret_cast<const f32x4*>(aff + d.C + 4 * q);
     const f32x4 mean = *reinterpret_cast<const f32x4*>(aff + 2 * d.C + 4 * q);
     const f32x4 istd = *reinterpret_cast<const f32x4*>(aff + 3 * d.C + 4 * q);
+    const bool flat = same_boxes(d, false);
     for (long vo = (long)blockIdx.x * nvl + vl; vo < nvox; vo += (long)gridDim.x * nvl) {
-      long v = vo;
-      const int x = v % d.Wo; v /= d.Wo;
-      const int yy = v % d.Ho; v /= d.Ho;
-      const int z = v % d.Do; const int b = v / d.Do;
-      const long vy = (((long)b * d.Dy + z) * d.Hy + yy) * d.Wy + x;
+      long vy = vo;
+      if (!flat) {
+        long v = vo;
+        const int x = v % d.Wo; v /= d.Wo;
+        const int yy = v % d.Ho; v /= d.Ho;
+        const int z = v % d.Do; const int b = v / d.Do;
+        vy = (((long)b * d.Dy + z) * d.Hy + yy) * d.Wy + x;
+      }
       const f32x4 yv = *reinterpret_cast<const f32x4*>(y + vy * d.C + 4 * q);
       f32x4 gv = *reinterpret_cast<const f32x4*>(g + vo * d.C + 4 * q);
       if (relu == 1) gv = mask4(gv, *reinterpret_cast<const f32x4*>(out + vo * d.C + 4 * q));
@@ -150,21 +167,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const long total = (long)d.B * Dm * Hm * Wm * nq;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int q = i % nq;
-  long v = i / nq;
-  const int x = v % Wm; v /= Wm;
-  const int yy = v % Hm; v /= Hm;
-  const int z = v % Dm; const int b = v / Dm;
-  const bool in_o = z < d.Do && yy < d.Ho && x < d.Wo;
-  const bool in_y = z < d.Dy && yy < d.Hy && x < d.Wy;
-  const bool in_r = dres && z < d.Dr && yy < d.Hr && x < d.Wr;
+  const int q = quad_of(i, nq);
+  const bool flat = same_boxes(d, dres != nullptr || d.Dr > 0);
+  bool in_o = true, in_y = true, in_r = dres != nullptr;
+  long vy = i / nq, vo_ = vy, vr_ = vy;
+  if (!flat) {
+    long v = i / nq;
+    const int x = v % Wm; v /= Wm;
+    const int yy = v % Hm; v /= Hm;
+    const int z = v % Dm; const int b = v / Dm;
+    in_o = z < d.Do && yy < d.Ho && x < d.Wo;
+    in_y = z < d.Dy && yy < d.Hy && x < d.Wy;
+    in_r = dres && z < d.Dr && yy < d.Hr && x < d.Wr;
+    vy = (((long)b * d.Dy + z) * d.Hy + yy) * d.Wy + x;
+    vo_ = (((long)b * d.Do + z) * d.Ho + yy) * d.Wo + x;
+    vr_ = (((long)b * d.Dr + z) * d.Hr + yy) * d.Wr + x;
+  }
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 gv = zero, graw = zero, yv = zero;
-  const long vy = (((long)b * d.Dy + z) * d.Hy + yy) * d.Wy + x;
   const f32x4 sc = *reinterpret_cast<const f32x4*>(aff + 4 * q);
   if (in_y) yv = *reinterpret_cast<const f32x4*>(y + vy * d.C + 4 * q);
   if (in_o) {
-    const long vo = (((long)b * d.Do + z) * d.Ho + yy) * d.Wo + x;
+    const long vo = vo_;
     graw = *reinterpret_cast<const f32x4*>(g + vo * d.C + 4 * q);
     gv = graw;
     if (relu == 1) gv = mask4(gv, *reinterpret_cast<const f32x4*>(out + vo * d.C + 4 * q));
@@ -180,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     *reinterpret_cast<f32x4*>(dy + vy * d.C + 4 * q) = sc * (gv - mg - xhat * mgx);
   }
   if (in_r) {
-    const long vr = (((long)b * d.Dr + z) * d.Hr + yy) * d.Wr + x;
+    const long vr = vr_;
     *reinterpret_cast<f32x4*>(dres + vr * d.C + 4 * q) = relu == 2 ? graw : gv;
   }
 }
