@@ -929,8 +929,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void deconv3d_cout1_kernel(ConvParams 
   constexpr int TY = 4, IZ = 2, IY = TY + 1, IX = 33, NQ = 8;
   constexpr int NE = IZ * IY * IX * NQ;                // 2640
   constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;  // 11
-  extern __shared__ __attribute__((aligned(16))) f32x4 tile[];   // box, then weights [27][8]
-  f32x4* wl = tile + NE;
+  extern __shared__ __attribute__((aligned(16))) f32x4 tile[];   // the input box (weights: scalar loads)
   const int tid = threadIdx.x;
   int id = blockIdx.x;
   const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
@@ -942,14 +941,18 @@ __global__ __launch_bounds__(NTHREADS, 3) void deconv3d_cout1_kernel(ConvParams 
   const StageBox box = stage_box(p.x, b, tz, ty0, tx0, p.Di, p.Hi, p.Wi, p.Cin, 0, IZ, IY, IX, true);
   f32x4 pf[NPF];
   stage_prefetch<NPF, NE, NQ, IX, IY>(pf, goff, box, xrsrc, tid);
-  for (int i = tid; i < 27 * NQ; i += NTHREADS) wl[i] = reinterpret_cast<const f32x4*>(p.w)[i];
   stage_commit<NPF, NE>(tile, pf, tid);
   __syncthreads();
   // thread -> (x position r, row ty, z-parity pz); pz is wave-uniform (waves 0-1: 0, 2-3: 1)
   const int r = tid & 31, ty = (tid >> 5) & 3, pz = tid >> 7;
   const int zo = 2 * tz + pz;
   if (zo >= p.Do) return;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};                 // class = py*2 + px
+  typedef float f32x2h __attribute__((ext_vector_type(2)));
+  typedef const float __attribute__((address_space(4))) cfloat;
+  typedef f32x4 __attribute__((address_space(4))) cquad;
+  cfloat* wc = (cfloat*)p.w;
+  asm volatile("" : "+s"(wc));                         // not loop-invariant as far as hipcc knows
+  f32x2h acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // class = py*2 + px; (even | odd channels)
   for (int iz = 0; iz <= pz; ++iz) {
     const int kz = pz ? (iz ? 0 : 2) : 1;
 #pragma unroll
@@ -963,15 +966,20 @@ __global__ __launch_bounds__(NTHREADS, 3) void deconv3d_cout1_kernel(ConvParams 
         const int py = c >> 1, px = c & 1;
         if (iy > py || ix > px) continue;
         const int ky = py ? (iy ? 0 : 2) : 1, kx = px ? (ix ? 0 : 2) : 1;
-        const f32x4* wt = wl + ((kz * 3 + ky) * 3 + kx) * NQ;
-        float a = acc[c];
+        // the tap's 32 weights as scalar loads (SGPR pairs), two channels per v_pk_fma_f32; even /
+        // odd channel sums are folded at the store (r02: 408 -> ... us; was LDS-broadcast weights and
+        // scalar FMAs)
+        f32x4 w4[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) w4[q] = *(const volatile cquad*)(wc + ((kz * 3 + ky) * 3 + kx) * 32 + q * 4);
+        f32x2h a = acc[c];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          const f32x4 w4 = wt[q];
-          a = fmaf(v[q].x, w4.x, a); a = fmaf(v[q].y, w4.y, a);
-          a = fmaf(v[q].z, w4.z, a); a = fmaf(v[q].w, w4.w, a);
+          a = __builtin_elementwise_fma(f32x2h{v[q].x, v[q].y}, f32x2h{w4[q].x, w4[q].y}, a);
+          a = __builtin_elementwise_fma(f32x2h{v[q].z, v[q].w}, f32x2h{w4[q].z, w4[q].w}, a);
         }
         acc[c] = a;
+        __builtin_amdgcn_sched_barrier(0);             // one tap's 32 SGPRs live at a time
       }
       // one offset's eight quads live at a time: left alone, hipcc hoists every LDS read of the
       // item to the top (256 VGPRs + AGPR spills, one wave per SIMD, 0.9 ms at GCNet's size)
@@ -985,7 +993,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void deconv3d_cout1_kernel(ConvParams 
   for (int c = 0; c < 4; ++c) {
     const int yo = 2 * ym + (c >> 1), xo = 2 * xm + (c & 1);
     if (yo >= p.Ho || xo >= p.Wo) continue;
-    float v = acc[c] * sc + sh;
+    float v = (acc[c].x + acc[c].y) * sc + sh;
     if (p.relu == 2) v = fmaxf(v, 0.f);
     if (p.res) v += p.res[(((long)b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo];
     if (p.relu == 1) v = fmaxf(v, 0.f);
