@@ -86,6 +86,7 @@ SIGNATURES = {
     "dsm_bn3d_train_bwd": (c_int, [ctypes.POINTER(Bn3dArgs), c_void_p]),
     "dsm_decoder_cat": (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p]),
     "dsm_stage_images_nhwc16": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "dsm_conv2d_first3_fwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
     "dsm_volume_relayout": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
     "dsm_conv_packed_weight_bytes": (ctypes.c_size_t, [c_int] * 4),
     "dsm_spp_branch_floats": (ctypes.c_size_t, [c_int] * 3),

@@ -448,7 +448,7 @@ import os as _os
 # DSM_CONV_PRECISION=fp32|bf16x3 so that scripts and the parity tests can switch whole runs
 _OPTIONS = {"s3": True, "fuse_volume": True, "s3in": False,
             "conv_fp32": _os.environ.get("DSM_CONV_PRECISION", "").startswith("f"),
-            "conv_flags": 0, "s3_tiling": 0, "overlap_heads": False}
+            "conv_flags": 0, "s3_tiling": 0, "overlap_heads": False, "first3": False}
 
 
 def set_option(name, value):
@@ -463,6 +463,9 @@ def set_option(name, value):
     more staged bytes and its producer an epilogue split.
     ``s3_tiling`` -- dsm_conv3d_s3_args.tiling of every S3 convolution launch (0 = the library's
     default, 1 = 8 x 32 tile / one workgroup per CU, 2 = 4 x 32 tile / two per CU);
+    ``first3`` -- PSMNet's first tower layer (3 -> 32, stride 2) runs on the VALU kernel straight from
+    the raw images instead of NHWC staging + the MFMA kernel (off: 55 us against 15 + 37 us, no gain
+    inside the forward -- profiles/r02_ablation.md section 6);
     ``overlap_heads`` -- PSMNet's eval forward runs classif1/classif2 and their soft-argmin heads on a
     second HIP stream beside the next hourglass (fork / join with events; a hipGraph captures both
     branches)."""
@@ -962,6 +965,29 @@ def stage_images_nhwc16(left, right=None):
     with torch.cuda.device(left.device):
         rc = _lib.load().dsm_stage_images_nhwc16(_p(left), _p(right), _p(out), B, C, H, W, _stream())
     _lib.check(rc, "dsm_stage_images_nhwc16")
+    return out
+
+
+def conv2d_first3(left, right, w_taps, scale=None, shift=None, relu=True):
+    """PSMNet's first tower layer straight from the raw NCHW images: Conv2d(3 -> 32, k3, s2, p1) with
+    the folded BN affine and ReLU, both views in one launch -> (2B or B, 32, H/2, W/2) channels_last.
+    ``w_taps``: the (32,3,3,3) weight as a contiguous (27, 32) tap-major tensor.  Inference only."""
+    _require_device("conv2d_first3", left, right, w_taps, scale, shift)
+    left = left.contiguous()
+    B, C, H, W = left.shape
+    if C != 3 or tuple(w_taps.shape) != (27, 32):
+        raise ValueError("conv2d_first3: a 3-channel image and (27, 32) tap-major weights are expected")
+    if right is not None:
+        if tuple(right.shape) != tuple(left.shape):
+            raise ValueError("conv2d_first3: the two views differ in shape")
+        right = right.contiguous()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty(((1 if right is None else 2) * B, 32, Ho, Wo), device=left.device,
+                      dtype=torch.float32, memory_format=_CL2D)
+    with torch.cuda.device(left.device), _timed("conv2d_first3_kernel", 2.0 * 27 * 32 * out.shape[0] * Ho * Wo):
+        rc = _lib.load().dsm_conv2d_first3_fwd(_p(left), _p(right), _p(w_taps), _p(scale), _p(shift),
+                                               _p(out), B, H, W, int(bool(relu)), _stream())
+    _lib.check(rc, "dsm_conv2d_first3_fwd")
     return out
 
 

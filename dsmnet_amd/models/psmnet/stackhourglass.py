@@ -104,9 +104,13 @@ class PSMNet(nn.Module):
         if self.training:
             return self.feature_extraction(left), self.feature_extraction(right)
         # eval: BN uses running statistics, so both views can share one batch
-        if left.is_cuda and not torch.is_grad_enabled() and left.shape[1] <= 16:
+        fe = self.feature_extraction
+        if left.is_cuda and not torch.is_grad_enabled() and fe.first_layer_fusable(left) and not cv.get_option("s3in"):
+            # the first layer of both views straight from the raw images, one launch
+            both = fe(left, first=fe.first_layer_of_pair(left, right))
+        elif left.is_cuda and not torch.is_grad_enabled() and left.shape[1] <= 16:
             # concatenation + NHWC staging (3 -> 16 channels) in one launch
-            both = self.feature_extraction(cv.stage_images_nhwc16(left, right), staged=True)
+            both = fe(cv.stage_images_nhwc16(left, right), staged=True)
         else:
             both = self.feature_extraction(torch.cat([left, right], dim=0))
         return both[: left.shape[0]], both[left.shape[0]:]

@@ -197,20 +197,50 @@ class feature_extraction(nn.Module):
                 raw = x_f
         return raw, x_f
 
-    def forward(self, x, staged=False):
+    def first_layer_of_pair(self, left, right=None):
+        """Eval fast path: firstconv[0] + BN + ReLU of both views straight from the raw NCHW images
+        (``costvolume.conv2d_first3``: one VALU launch instead of NHWC staging + the MFMA kernel).
+        Returns the (2B or B, 32, H/2, W/2) channels_last map for ``forward(..., first=...)``."""
+        conv, bn = self.firstconv[0][0], self.firstconv[0][1]
+        srcs = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = _versions(*srcs)
+        if self.__dict__.get("_first_key") != key:
+            with torch.no_grad():
+                inv = torch.rsqrt(bn.running_var + bn.eps)
+                scale = (bn.weight * inv).contiguous()
+                shift = (bn.bias - bn.running_mean * scale).contiguous()
+                w_taps = conv.weight.reshape(32, 27).t().contiguous()
+            self.__dict__["_first_cache"] = (w_taps, scale, shift)
+            self.__dict__["_first_key"] = key
+        w_taps, scale, shift = self.__dict__["_first_cache"]
+        return cv.conv2d_first3(left, right, w_taps, scale, shift, relu=True)
+
+    def first_layer_fusable(self, x):
+        conv = self.firstconv[0][0]
+        return (x.is_cuda and x.dtype == torch.float32 and not self.training and not torch.is_grad_enabled()
+                and x.shape[1] == 3 and conv.in_channels == 3 and conv.out_channels == 32 and
+                conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and
+                conv.dilation == (1, 1) and conv.bias is None and cv.get_option("first3"))
+
+    def forward(self, x, staged=False, first=None):
         """``staged``: ``x`` is already the (B,16,H,W) NHWC staging of the image(s)
-        (``costvolume.stage_images_nhwc16``; eval fast path only)."""
-        fast = x.is_cuda and not self.training and not torch.is_grad_enabled()
-        if staged and not fast:
+        (``costvolume.stage_images_nhwc16``); ``first``: the output of ``first_layer_of_pair`` (``x`` is
+        then ignored).  Both on the eval fast path only."""
+        fast = (x if first is None else first).is_cuda and not self.training and not torch.is_grad_enabled()
+        if (staged or first is not None) and not fast:
             raise RuntimeError("feature_extraction: staged input exists on the eval fast path only")
-        if fast and cv.get_option("s3") and cv.get_option("s3in") and cv.get_option_bf16x3():
+        if first is None and fast and not staged and self.first_layer_fusable(x):
+            first = self.first_layer_of_pair(x)
+        if first is None and fast and cv.get_option("s3") and cv.get_option("s3in") and cv.get_option_bf16x3():
             raw, skip = self._trunk_s3(x, staged)
         else:
-            if fast and not staged:
+            if first is not None:
+                x = first
+            elif fast and not staged:
                 x = stage_image_nhwc16(x)                  # NHWC, 3 -> 16 staged channels
             elif _TRAIN_NHWC and x.is_cuda:
                 x = x.contiguous(memory_format=torch.channels_last)
-            for i in (0, 2, 4):
+            for i in ((2, 4) if first is not None else (0, 2, 4)):
                 x = self.firstconv[i](x, relu=True)
             x = self.layer1(x)
             raw = self.layer2(x)

@@ -377,6 +377,15 @@ int dsm_decoder_cat(const void* up, const void* bias, const void* pr, const void
                     int B, int Cu, int Cp, int Cs, int Hu, int Wu, int Hp, int Wp, int Hs, int Ws,
                     int relu, dsm_stream_t stream);
 
+/* (ABI v5) PSMNet's first tower layer on the raw images, both views in one launch:
+ *   out = relu?( conv2d(img, w; k3, stride 2, pad 1) * scale + shift )   (submodule.py:70-72, 10-13)
+ * left, right (B,3,H,W) NCHW fp32 (right = NULL: one view); w_taps [27][32]: the (32,3,3,3) torch
+ * weight transposed to tap-major (tap = (c*3 + ky)*3 + kx); scale / shift [32] or NULL;
+ * out (2B or B, 32, Ho, Wo) in NHWC memory, Ho = (H-1)/2 + 1.  Exact fp32 FMAs on the VALU. */
+int dsm_conv2d_first3_fwd(const void* left, const void* right, const void* w_taps, const float* scale,
+                          const float* shift, void* out, int B, int H, int W, int relu,
+                          dsm_stream_t stream);
+
 /* (ABI v5) Image staging of the 2-D towers (models/psmnet/stackhourglass.py:118-121 feeds the two
  * views through feature_extraction one after the other; in eval mode they share one batch):
  * left, right (B,C,H,W) NCHW fp32, C <= 16 -> out (2B,16,H,W) in NHWC memory, channels C..15 zero.

@@ -21,7 +21,7 @@ m.eval()
 # (s3, fuse_volume, s3_tiling, overlap_heads); s3in stays off
 configs = {"s3+fuse": (True, True, 0, False), "s3": (True, False, 0, False), "r01": (False, False, 0, False),
            "tile8x32": (True, True, 1, False), "tile4x32": (True, True, 2, False),
-           "overlap": (True, True, 0, True)}
+           "overlap": (True, True, 0, True), "nofirst3": (True, True, 0, False)}
 GRAPH = "--graph" in sys.argv                      # time hipGraph replays instead of eager launches
 sys.argv = [a for a in sys.argv if a != "--graph"]
 if len(sys.argv) > 1:
@@ -35,6 +35,7 @@ with torch.no_grad():
         for name, (s3, fuse, tiling, overlap) in configs.items():
             cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse), cv.set_option("s3_tiling", tiling)
             cv.set_option("overlap_heads", overlap)
+            cv.set_option("first3", name != "nofirst3")
             if GRAPH:
                 if name not in graphs:
                     graphs[name] = GraphedForward(m, l, r)
@@ -53,6 +54,7 @@ with torch.no_grad():
     for name, (s3, fuse, tiling, overlap) in configs.items():
         cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse), cv.set_option("s3_tiling", tiling)
         cv.set_option("overlap_heads", False)
+        cv.set_option("first3", name != "nofirst3")
         t = cv.LaunchTimer()
         cv.set_timer(t)
         for _ in range(5):

@@ -256,8 +256,9 @@ def test_psmnet_raw_init_is_no_worse_than_the_cpu_fp32_path(hip_lib, golden_e2e)
     truth than the CPU fp32 path is, up to the scatter between two fp32 summation orders: factor
     2 on the largest and on the mean error of each head.  Which near-ties flip is chaotic (the
     largest error is one pixel's): measured r02 on two kernel generations, max 1.0-1.55x and
-    mean 1.3-1.6x of the CPU path's; a precision bug (a dropped bf16 term costs 2^-16 relative)
-    moves the mean by orders of magnitude."""
+    mean 1.3-1.6x of the CPU path's (a third one -- the opt-in VALU first layer, exact fp32 FMAs --
+    gave 2.01x on one head's largest error); a precision bug (a dropped bf16 term costs 2^-16
+    relative) moves the mean by orders of magnitude."""
     from oracle import ops as OO
     sd, cfg = golden_state(golden_e2e, "psmnet")
     raw = 1.0 / float(golden_e2e.z["e2e.psmnet.head_scale"])      # undo the calibration of the heads
