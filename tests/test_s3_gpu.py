@@ -79,6 +79,36 @@ def test_conv3d_s3_vs_cpu_fp64(cv, shape, cin, relu, res_shape, grid):
     assert torch.equal(only.buf, ys3.buf)
 
 
+@pytest.mark.parametrize("shape,cin,relu,res_shape,grid,virtual", [
+    ((1, 6, 12, 40), 32, 1, None, 0, False),
+    ((2, 5, 9, 33), 64, 2, (5, 9, 33), 7, False),       # ragged tiles (4-row tiles: 3 + partial), batch 2
+    ((1, 13, 17, 70), 32, 1, (12, 16, 69), 5, False),   # cropped skip
+    ((1, 9, 11, 53), 64, 1, None, 9, True),             # the virtual cost volume as input
+])
+def test_conv3d_s3_second_tiling_is_bit_identical(cv, shape, cin, relu, res_shape, grid, virtual):
+    """dsm_conv3d_s3_args.tiling = 2 (4 x 32 tiles, two workgroups per CU, waves split over couts)
+    computes the same arithmetic in the same order as tiling = 1: identical bits on both outputs."""
+    B, D, H, W = shape
+    w = seeded(22, 32, cin, 3, 3, 3, scale=(2.0 / (27 * cin)) ** 0.5).cuda()
+    scale, shift = (seeded(23, 32).abs() + 0.5).cuda(), seeded(24, 32).cuda()
+    res = seeded(25, B, 32, *res_shape).cuda() if res_shape else None
+    if virtual:
+        fL, fR = seeded(41, B, cin // 2, H, W).cuda(), seeded(42, B, cin // 2, H, W).cuda()
+        xs = cv.concat_volume_s3(fL, fR, D, True, materialise=False)
+    else:
+        xs = cv.s3_from_tensor(seeded(21, B, cin, D, H, W).cuda())
+    packed = cv.pack_conv3d_s3_weight(w)
+    got = {}
+    for tiling in (1, 2):
+        old = cv.set_option("s3_tiling", tiling)
+        try:
+            got[tiling] = cv.conv3d_s3_block(xs, packed, scale, shift, res, relu=relu, out="both", grid=grid)
+        finally:
+            cv.set_option("s3_tiling", old)
+    assert torch.equal(got[1][0], got[2][0])
+    assert torch.equal(got[1][1].buf, got[2][1].buf)
+
+
 def test_conv3d_s3_agrees_with_the_fp32_input_mfma_kernel(cv):
     """Same layer on the exact-fp32 MFMA kernel (conv3d.hip) and on the z-sliding bf16x3 kernel."""
     x = seeded(31, 1, 32, 7, 19, 45)
