@@ -16,6 +16,7 @@ DSM_OK = 0
 DSM_F32 = 0
 DSM_NCDHW, DSM_NDHWC = 0, 1
 DSM_CONV_FP32_MFMA, DSM_CONV_COUT1_CHUNKED, DSM_CONV_TM_SHIFT, DSM_CONV_BLOCKS_SHIFT = 1, 2, 4, 16
+DSM_CONV_NO_NSPLIT = 4
 
 
 class Bn3dArgs(ctypes.Structure):

@@ -1066,7 +1066,7 @@ int run_conv(ConvParams p, hipStream_t s, int nsplit = 1) {
   return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK, KZ, KXY, DIL>, p, lds, s, 512 / nsplit, nsplit);
 }
 
-template <int NT, int TM, int KZ, int DIL, int S = 1, bool S3IN = false>
+template <int NT, int TM, int KZ, int DIL, int S = 1, bool S3IN = false, int NSPLIT = 1>
 int run_conv_bf16x3(ConvParams p, hipStream_t s) {
   constexpr int TY = 4 * TM, IY = (TY - 1) * S + 2 * DIL + 1, IX = 31 * S + 2 * DIL + 1;
   constexpr int NPF = (IY * IX * 4 + NTHREADS - 1) / NTHREADS;
@@ -1075,12 +1075,14 @@ int run_conv_bf16x3(ConvParams p, hipStream_t s) {
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
   // two images; one workgroup per CU, or two where conv_bf16x3_two_per_cu says both fit
-  constexpr bool TWO = conv_bf16x3_two_per_cu<NT, TM, S, S3IN>();
+  constexpr bool TWO = conv_bf16x3_two_per_cu<NT, TM, S, S3IN, DIL>();
   const size_t lds = ((S == 1 && !S3IN) ? (size_t)2 * (TWO ? (IY * IX + 4) * 112 : NPF * 64 * 112)
                                        : (size_t)2 * (IY * (S == 1 ? IX : 66) + 4) * 112) +
-                     2 * 32 * NT * sizeof(float);                    // + scale / shift
-  static_assert(!TWO || 2 * (2 * (IY * IX + 4) * 112 + 2 * 32 * NT * 4) <= 160 * 1024, "two workgroups per CU");
-  return launch_tiles(conv_bf16x3_kernel<NT, TM, KZ, DIL, S, S3IN>, p, lds, s, TWO ? 512 : 256);
+                     2 * 32 * NT * NSPLIT * sizeof(float);           // + scale / shift of the whole layer
+  static_assert(!TWO || 2 * (2 * (IY * IX + 4) * 112 + 2 * 32 * NT * NSPLIT * 4) <= 160 * 1024, "two workgroups per CU");
+  static_assert(NSPLIT == 1 || TWO, "the N-split exists to put two workgroup columns on a CU");
+  return launch_tiles(conv_bf16x3_kernel<NT, TM, KZ, DIL, S, S3IN, NSPLIT>, p, lds, s,
+                      (TWO ? 512 : 256) / NSPLIT, NSPLIT);
 }
 
 template <int NT>
@@ -1255,6 +1257,12 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
     if (NT == 2 && dil == 1 && tiles8 < 192) TM = 1;
     if (force_tm == 2 || (force_tm == 4 && NT == 1 && dil == 1) || (force_tm == 1 && NT == 2 && dil == 1)) TM = force_tm;
     *pl = Plan{5, 1, NT, TM, 16, kd, 3, dil};
+    // N-split (2-D layers, fp32 input): at most one round of 8-row tiles -- every workgroup's prologue
+    // and epilogue exposed -- becomes two workgroup columns of half the output blocks, two per CU
+    if (kd == 1 && !a->x_s3 && TM == 2 && dil == 1 && (NT == 2 || NT == 4) && tiles8 <= 256 &&
+        !(a->flags & DSM_CONV_NO_NSPLIT)) {
+      pl->NT = NT / 2; pl->nsplit = 2;
+    }
     return DSM_OK;
   }
   if (a->stride == 2 && kd == 3 && NT == 2 && bf16x3_enabled(a) &&
@@ -1299,6 +1307,7 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
     case 5:
       if (pl.KZ == 3 && pl.S == 2) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<S=2,NT=%d,TM=%d%s>", pl.NT, pl.TM, a->x_s3 ? ",S3IN" : "");
       else if (pl.KZ == 3) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d%s>", pl.NT, pl.TM, a->x_s3 ? ",S3IN" : "");
+      else if (pl.nsplit > 1) snprintf(buf, len, "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>x%d", pl.NT, pl.TM, pl.DIL, pl.nsplit);
       else snprintf(buf, len, "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d%s>", pl.NT, pl.TM, pl.DIL, a->x_s3 ? ",S3IN" : "");
       break;
     case 6: snprintf(buf, len, "deconv3d_bf16x3_mfma_kernel<NT=%d>", pl.NT); break;
@@ -1351,6 +1360,11 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
     p.w = (const float*)a->w_packed + (size_t)a->Cin * a->Cout * pl.KZ * 9;   // section 2
     p.wbytes = (unsigned)bf16x3_section_bytes(a->Cin, a->Cout, pl.KZ, 3);
     if (pl.S == 2) return a->x_s3 ? run_conv_bf16x3<2, 1, 3, 1, 2, true>(p, s) : run_conv_bf16x3<2, 1, 3, 1, 2>(p, s);
+    if (pl.nsplit == 2) {                         // 2-D layers of 64 / 128 channels in two workgroup columns
+      if (pl.NT == 1 && pl.TM == 2 && pl.DIL == 1) return run_conv_bf16x3<1, 2, 1, 1, 1, false, 2>(p, s);
+      if (pl.NT == 2 && pl.TM == 2 && pl.DIL == 1) return run_conv_bf16x3<2, 2, 1, 1, 1, false, 2>(p, s);
+      return DSM_ERR_UNSUPPORTED;
+    }
 #define DSM_CASE_BF(NT_, TM_, KZ_, DIL_) \
     if (pl.NT == NT_ && pl.TM == TM_ && pl.KZ == KZ_ && pl.DIL == DIL_) \
       return a->x_s3 ? run_conv_bf16x3<NT_, TM_, KZ_, DIL_, 1, true>(p, s) : run_conv_bf16x3<NT_, TM_, KZ_, DIL_>(p, s)

@@ -91,11 +91,15 @@ __device__ __forceinline__ Affine load_affine_lds(const float* aff, int cout, in
 // images) let TWO workgroups share a CU: the second one computes while the first one's prologue /
 // epilogue runs -- what the transposed kernel gained 7-12 % from.  (The 16-row and 128-channel
 // variants need one CU's LDS or registers for themselves.)
-template <int NT, int TM, int S, bool S3IN>
-constexpr bool conv_bf16x3_two_per_cu() { return S == 1 && !S3IN && NT <= 2 && TM <= 2; }
+template <int NT, int TM, int S, bool S3IN, int DIL = 1>
+constexpr bool conv_bf16x3_two_per_cu() { return S == 1 && !S3IN && NT <= 2 && TM <= 2 && DIL == 1; }
 
-template <int NT, int TM, int KZ, int DIL, int S = 1, bool S3IN = false>
-__global__ __launch_bounds__(NTHREADS, (conv_bf16x3_two_per_cu<NT, TM, S, S3IN>() ? 2 : 1))
+// NSPLIT > 1 (N-split): the layer has NT * NSPLIT 32-channel output blocks and workgroup column
+// blockIdx.y computes NT of them -- a 128-channel 2-D layer with 240 tiles becomes 480 workgroups of
+// the 64-channel variant, two per CU, instead of 240 that leave every CU's prologue and epilogue
+// exposed (each workgroup stages the whole input tile; the weights are read once either way).
+template <int NT, int TM, int KZ, int DIL, int S = 1, bool S3IN = false, int NSPLIT = 1>
+__global__ __launch_bounds__(NTHREADS, (conv_bf16x3_two_per_cu<NT, TM, S, S3IN, DIL>() ? 2 : 1))
 void conv_bf16x3_kernel(ConvParams p) {
   static_assert(S == 1 || (S == 2 && DIL == 1 && KZ == 3), "stride 2: 3x3x3, no dilation");
   constexpr int TY = 4 * TM, NQ = S3IN ? 6 : 4, CK = 16;
@@ -105,7 +109,7 @@ void conv_bf16x3_kernel(ConvParams p) {
   constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
   constexpr int PITCH = 112;                    // bytes per voxel in LDS: 3 planes x 32 B + 16 pad
   constexpr int RP = (S == 1) ? IX : 66;        // voxels per image row
-  constexpr bool TWO = conv_bf16x3_two_per_cu<NT, TM, S, S3IN>();
+  constexpr bool TWO = conv_bf16x3_two_per_cu<NT, TM, S, S3IN, DIL>();
   // fp32 input, S = 1: the last pass's tail quads land in padding behind the image -- or, where two
   // workgroups share the CU, are not stored (exact-size image)
   constexpr int IMG = (S == 1 && !S3IN) ? (TWO ? (NVOX + 4) * PITCH : NPF * 64 * PITCH) : (IY * RP + 4) * PITCH;
@@ -123,12 +127,14 @@ void conv_bf16x3_kernel(ConvParams p) {
   constexpr int CPG = S3IN ? LPG : (2 * NPF + (NGROUP - CONV0) - 1) / (NGROUP - CONV0);   // halves (stores) per group
   static_assert(NPF <= NGROUP * LPG && CONV0 >= 2, "staging schedule");
   static_assert(!S3IN || CONV0 > (NPF + LPG - 1) / LPG, "a store must come after its load");
-  constexpr int COUT = 32 * NT;
+  constexpr int NTP = NT * NSPLIT;              // 32-channel output blocks of the layer
+  constexpr int COUT = 32 * NTP;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nch = p.Cin / CK;
+  const int n0 = NSPLIT > 1 ? (int)blockIdx.y * NT : 0;      // first output block of this workgroup column
 
   int step, end;
   int t = first_tile(p.ntiles, step, end);
@@ -197,7 +203,9 @@ void conv_bf16x3_kernel(ConvParams p) {
     return q.t < end && zin >= 0 && zin < p.Di;
   };
   // weights: [ck][dz][tap9][n][plane][lane][16 B]
-  auto wbase_of = [&](const Pos& q) { return (unsigned)((q.ck * KZ + q.dz) * 9) * (NT * 3 * 64 * 16); };
+  auto wbase_of = [&](const Pos& q) {
+    return (unsigned)((q.ck * KZ + q.dz) * 9) * (NTP * 3 * 64 * 16) + (unsigned)n0 * (3 * 64 * 16);
+  };
 
   // LDS write address of this thread's quad k.  S = 1: voxel (tid >> 2) + 64 k, an immediate
   // per k; S = 2: the even/odd row layout, one register per k.
@@ -269,7 +277,7 @@ void conv_bf16x3_kernel(ConvParams p) {
 #pragma unroll
       for (int q = 0; q < 3; ++q)
         wq[item % AHEAD][n][q] = __builtin_bit_cast(
-            bf16x8, buffer_load16(wrsrc, lane16, wb + ((item * NT + n) * 3 + q) * (64 * 16)));
+            bf16x8, buffer_load16(wrsrc, lane16, wb + ((item * NTP + n) * 3 + q) * (64 * 16)));
   };
 
   float* const aff = reinterpret_cast<float*>(lds_raw + 2 * IMG);
@@ -281,7 +289,7 @@ void conv_bf16x3_kernel(ConvParams p) {
     static_for<0, NPF>([&](auto kc) {
       pf[decltype(kc)::value] = buffer_load16(rs0, voff[decltype(kc)::value], 0);
     });
-    static_for<0, AHEAD - 1>([&](auto ic) { wload(ic, 0u); });
+    static_for<0, AHEAD - 1>([&](auto ic) { wload(ic, wbase_of(cur_pos)); });
     static_for<0, NPF>([&](auto kc) {
       convert(kc, std::integral_constant<int, 0>{}, lds_raw);
       if constexpr (!S3IN) convert(kc, std::integral_constant<int, 1>{}, lds_raw);
@@ -305,7 +313,7 @@ void conv_bf16x3_kernel(ConvParams p) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
     }
-    const unsigned wchunk = wbase_of(cur_pos), wnext = nxt.t < end ? wbase_of(nxt) : 0u;
+    const unsigned wchunk = wbase_of(cur_pos), wnext = nxt.t < end ? wbase_of(nxt) : wbase_of(cur_pos);
     bf16x8 xq[2][3];
     auto xload = [&](auto sc) {                 // s = item * TM + m
       constexpr int s = decltype(sc)::value;
@@ -380,7 +388,7 @@ void conv_bf16x3_kernel(ConvParams p) {
       const int xo = tx0 + r;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const int cbase = n * 32 + 4 * h;
+        const int cbase = (n0 + n) * 32 + 4 * h;
         const Affine af = load_affine_lds(aff, COUT, cbase);
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
@@ -391,7 +399,7 @@ void conv_bf16x3_kernel(ConvParams p) {
           if (p.ys3)
             store_tile_s3<COUT>(acc[m][n], af, p.relu, p.y ? p.y + vox * COUT + cbase : nullptr,
                                 p.res ? p.res + rvox * COUT + cbase : nullptr,
-                                p.ys3 + (((((long)tb * p.Do + tz) * p.Ho + yo) * NT + n) * 12) * p.Wo * 16,
+                                p.ys3 + (((((long)tb * p.Do + tz) * p.Ho + yo) * NTP + n0 + n) * 12) * p.Wo * 16,
                                 xo, p.Wo, h);
           else
           store_tile<COUT>(acc[m][n], af, p.relu, p.y + vox * COUT + cbase,

@@ -7,8 +7,9 @@ import torch
 
 from dsmnet_amd import _lib, costvolume as cv
 
-cin, cout, H, W, B = (int(v) for v in sys.argv[1:6]) if len(sys.argv) > 5 else (64, 64, 96, 320, 2)
-D = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+cin, cout, H, W, B = (int(v) for v in argv[:5]) if len(argv) > 4 else (64, 64, 96, 320, 2)
+D = int(argv[5]) if len(argv) > 5 else 1
 _lib.load()
 torch.manual_seed(0)
 if D > 1:
@@ -19,8 +20,8 @@ else:
     x = torch.randn(B, cin, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
     packed = cv.pack_conv2d_weight(torch.randn(cout, cin, 3, 3, device="cuda") * 0.05)
     run = lambda: cv.conv2d_block(x, packed, cout, relu=1)
-variants = {"default": 0}
-for tm in (1, 2, 4):
+variants = {"default": 0, "no N-split": _lib.DSM_CONV_NO_NSPLIT}
+for tm in (() if "--nsplit" in sys.argv else (1, 2, 4)):
     for blocks in (0, 512, 768):
         variants["TM=%d,blocks=%d" % (tm, blocks)] = (tm << _lib.DSM_CONV_TM_SHIFT) | (blocks << _lib.DSM_CONV_BLOCKS_SHIFT)
 times = {k: [] for k in variants}
