@@ -27,9 +27,12 @@ def plan_name(n):
                 "conv2d_mfma_kernel<S=%d,NT=%d,TM=%d,K=%d,DIL=%d>" % (S, NT, TM, K, DIL))
     if n.startswith("conv_s3_kernel"):
         return "conv3d_s3_bf16x3_mfma_kernel"
-    m = re.match(r"conv_bf16x3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:false|true))?>", n)
+    m = re.match(r"conv_bf16x3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:false|true))?(?:, (\d+))?>", n)
     if m:
-        NT, TM, KZ, DIL, S = map(int, m.groups())
+        NT, TM, KZ, DIL, S = map(int, m.groups()[:5])
+        nsplit = int(m.group(6) or 1)
+        if nsplit > 1:
+            return "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>x%d" % (NT, TM, DIL, nsplit)
         if S == 2:
             return "conv3d_bf16x3_mfma_kernel<S=2,NT=%d,TM=%d>" % (NT, TM)
         return ("conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>" % (NT, TM) if KZ == 3 else
