@@ -1263,6 +1263,13 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
         !(a->flags & DSM_CONV_NO_NSPLIT)) {
       pl->NT = NT / 2; pl->nsplit = 2;
     }
+    // the 64-channel 3-D layers on 4-row tiles (the bottom of the hourglass: 216 tiles, one serial chain
+    // of 1,296 MFMAs per wave): two columns of 32 channels halve the chain
+    // (one round of tiles only: 43.0 vs 44.7 us with 216 tiles; with 432 the two columns queue: 72.5 vs 67.4)
+    if (kd == 3 && !a->x_s3 && TM == 1 && NT == 2 && !(a->flags & DSM_CONV_NO_NSPLIT) &&
+        (long)a->B * a->Do * dsm_cdiv(a->Ho, 4) * dsm_cdiv(a->Wo, 32) <= 256) {
+      pl->NT = 1; pl->nsplit = 2;
+    }
     return DSM_OK;
   }
   if (a->stride == 2 && kd == 3 && NT == 2 && bf16x3_enabled(a) &&
@@ -1306,6 +1313,7 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
     case 4: snprintf(buf, len, "conv3d_cout1_zslide_kernel"); break;
     case 5:
       if (pl.KZ == 3 && pl.S == 2) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<S=2,NT=%d,TM=%d%s>", pl.NT, pl.TM, a->x_s3 ? ",S3IN" : "");
+      else if (pl.KZ == 3 && pl.nsplit > 1) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>x%d", pl.NT, pl.TM, pl.nsplit);
       else if (pl.KZ == 3) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d%s>", pl.NT, pl.TM, a->x_s3 ? ",S3IN" : "");
       else if (pl.nsplit > 1) snprintf(buf, len, "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>x%d", pl.NT, pl.TM, pl.DIL, pl.nsplit);
       else snprintf(buf, len, "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d%s>", pl.NT, pl.TM, pl.DIL, a->x_s3 ? ",S3IN" : "");
@@ -1361,8 +1369,9 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
     p.wbytes = (unsigned)bf16x3_section_bytes(a->Cin, a->Cout, pl.KZ, 3);
     if (pl.S == 2) return a->x_s3 ? run_conv_bf16x3<2, 1, 3, 1, 2, true>(p, s) : run_conv_bf16x3<2, 1, 3, 1, 2>(p, s);
     if (pl.nsplit == 2) {                         // 2-D layers of 64 / 128 channels in two workgroup columns
-      if (pl.NT == 1 && pl.TM == 2 && pl.DIL == 1) return run_conv_bf16x3<1, 2, 1, 1, 1, false, 2>(p, s);
-      if (pl.NT == 2 && pl.TM == 2 && pl.DIL == 1) return run_conv_bf16x3<2, 2, 1, 1, 1, false, 2>(p, s);
+      if (pl.KZ == 1 && pl.NT == 1 && pl.TM == 2 && pl.DIL == 1) return run_conv_bf16x3<1, 2, 1, 1, 1, false, 2>(p, s);
+      if (pl.KZ == 1 && pl.NT == 2 && pl.TM == 2 && pl.DIL == 1) return run_conv_bf16x3<2, 2, 1, 1, 1, false, 2>(p, s);
+      if (pl.KZ == 3 && pl.NT == 1 && pl.TM == 1) return run_conv_bf16x3<1, 1, 3, 1, 1, false, 2>(p, s);
       return DSM_ERR_UNSUPPORTED;
     }
 #define DSM_CASE_BF(NT_, TM_, KZ_, DIL_) \

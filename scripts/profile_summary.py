@@ -31,6 +31,8 @@ def plan_name(n):
     if m:
         NT, TM, KZ, DIL, S = map(int, m.groups()[:5])
         nsplit = int(m.group(6) or 1)
+        if nsplit > 1 and KZ == 3:
+            return "conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>x%d" % (NT, TM, nsplit)
         if nsplit > 1:
             return "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>x%d" % (NT, TM, DIL, nsplit)
         if S == 2:
