@@ -359,12 +359,33 @@ __global__ __launch_bounds__(256) void soft_argmin_bwd_tile_kernel(SaBwdParams p
     st.wy0 = ly.w0; st.wy1 = ly.w1; st.wx0 = lx.w0; st.wx1 = lx.w1;
     const int l00 = (ly.i0 - cy0) * cw + (lx.i0 - cx0), l01 = (ly.i0 - cy0) * cw + (lx.i1 - cx0);
     const int l10 = (ly.i1 - cy0) * cw + (lx.i0 - cx0), l11 = (ly.i1 - cy0) * cw + (lx.i1 - cx0);
+    // Pixels of one row that share the coarse column pair (lx.i0, lx.i1) are a contiguous run of lanes
+    // (the indices are monotonic in x; four lanes at the x4 upsampling).  Their contributions are
+    // summed across the run first (segmented suffix sums by doubling, 2 x 5 lane shuffles) and only the
+    // run's first lane adds to the cell: 4-way fewer LDS atomics on the same address per row, and the
+    // two rows of a wave that share a coarse row are all that is left to collide.
+    bool same[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int o = 1 << j;
+      const int ki = __shfl_down(lx.i0, o, 32), kj = __shfl_down(lx.i1, o, 32);
+      same[j] = tx + o < SAB_TX && ki == lx.i0 && kj == lx.i1 && x + o < p.W;
+    }
+    const int kp0 = __shfl_up(lx.i0, 1, 32), kp1 = __shfl_up(lx.i1, 1, 32);
+    const bool leader = tx == 0 || kp0 != lx.i0 || kp1 != lx.i1;
     auto scatter_lds = [&](int k, float a) {
+      float r0 = a * st.wx0, r1 = a * st.wx1;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const float o0 = __shfl_down(r0, 1 << j, 32), o1 = __shfl_down(r1, 1 << j, 32);
+        if (same[j]) { r0 += o0; r1 += o1; }
+      }
+      if (!leader) return;
       float* q = cell + (k - k0) * pc;
-      __hip_atomic_fetch_add(q + l00, a * st.wy0 * st.wx0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(q + l01, a * st.wy0 * st.wx1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(q + l10, a * st.wy1 * st.wx0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(q + l11, a * st.wy1 * st.wx1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(q + l00, r0 * st.wy0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(q + l01, r1 * st.wy0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(q + l10, r0 * st.wy1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(q + l11, r1 * st.wy1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     const long ps = (long)p.Hc * p.Wc;
     const float* base = p.cost + (long)b * p.Dc * ps;
