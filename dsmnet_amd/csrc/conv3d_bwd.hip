@@ -511,6 +511,54 @@ __global__ __launch_bounds__(256) void cout1_bwd_data_kernel(const float* __rest
   *reinterpret_cast<f32x4*>(dx + i * 4) = a;
 }
 
+// The same for C = 32 with a thread per VOXEL: the 27 neighbouring g values are loaded once for all
+// 32 channels (the kernel above loads them once per channel quad), the tap's 32 weights come as scalar
+// loads (SGPR pairs) and the 864 MACs issue as 432 v_pk_fma_f32; the voxel's 128 bytes leave as eight
+// 16-byte stores.  88 -> 52 us at 48 x 64 x 128.
+__global__ __launch_bounds__(256) void cout1_bwd_data32_kernel(const float* __restrict__ g,
+                                                               const float* __restrict__ w,  // [27][32]
+                                                               float* __restrict__ dx, int B, int D,
+                                                               int H, int W) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef const float __attribute__((address_space(4))) cfloat;
+  typedef f32x4 __attribute__((address_space(4))) cquad;
+  const long n = (long)B * D * H * W;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  long v = i;
+  const int x = v % W; v /= W;
+  const int y = v % H; v /= H;
+  const int z = v % D; const int b = v / D;
+  float gn[27];
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap) {
+    const int zz = z - tap / 9 + 1, yy = y - (tap / 3) % 3 + 1, xx = x - tap % 3 + 1;
+    gn[tap] = (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                  ? g[(((long)b * D + zz) * H + yy) * W + xx] : 0.f;
+  }
+  cfloat* wc = (cfloat*)w;
+  asm volatile("" : "+s"(wc));
+  f2 acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = f2{0.f, 0.f};
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap) {
+    f32x4 w4[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w4[q] = *(const volatile cquad*)(wc + tap * 32 + q * 4);
+    const f2 g2 = {gn[tap], gn[tap]};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      acc[2 * q] = __builtin_elementwise_fma(g2, f2{w4[q].x, w4[q].y}, acc[2 * q]);
+      acc[2 * q + 1] = __builtin_elementwise_fma(g2, f2{w4[q].z, w4[q].w}, acc[2 * q + 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  f32x4* dst = reinterpret_cast<f32x4*>(dx + i * 32);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) dst[q] = f32x4{acc[2 * q].x, acc[2 * q].y, acc[2 * q + 1].x, acc[2 * q + 1].y};
+}
+
 // bwd-weight: dw[tap][c] = sum_v x[v+tap-1][c] g[v];  block = one (b, z, y) row, lanes over c,
 // partial sums per block leave as atomics into dw (27*C floats).
 __global__ __launch_bounds__(256) void cout1_bwd_weight_kernel(const float* __restrict__ x,
@@ -746,8 +794,12 @@ extern "C" int dsm_conv3d_cout1_bwd(const void* x, const void* g, const void* w_
   if (dx) {
     DSM_REQUIRE(w_packed, DSM_ERR_ARG);
     const long n = (long)B * D * H * W * (C / 4);
-    hipLaunchKernelGGL(cout1_bwd_data_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s,
-                       (const float*)g, (const float*)w_packed, (float*)dx, B, C, D, H, W);
+    if (C == 32 && dsm_aligned16(w_packed) && dsm_aligned16(dx))
+      hipLaunchKernelGGL(cout1_bwd_data32_kernel, dim3(dsm_cdiv(n / 8, 256)), dim3(256), 0, s,
+                         (const float*)g, (const float*)w_packed, (float*)dx, B, D, H, W);
+    else
+      hipLaunchKernelGGL(cout1_bwd_data_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s,
+                         (const float*)g, (const float*)w_packed, (float*)dx, B, C, D, H, W);
   }
   if (dw_tapmajor) {
     DSM_REQUIRE(x, DSM_ERR_ARG);
