@@ -30,7 +30,7 @@ from .blocks3d import _versions
 _TRAIN_2D_MODE = __import__("os").environ.get("DSM_TRAIN_2D", "auto")
 _FUSED_TRAIN_2D = _TRAIN_2D_MODE in ("auto", "fused", "conv")
 _FUSED_TRAIN_2D_BN = _TRAIN_2D_MODE == "fused"
-_TRAIN_2D_MIN_PIXELS = 65536 if _TRAIN_2D_MODE == "auto" else 0
+_TRAIN_2D_MIN_PIXELS = int(__import__("os").environ.get("DSM_TRAIN_2D_MIN_PIXELS", 65536)) if _TRAIN_2D_MODE == "auto" else 0
 
 
 def s3in_ok(conv):
