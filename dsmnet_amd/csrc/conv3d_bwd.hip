@@ -603,30 +603,56 @@ __global__ __launch_bounds__(256) void cout1_bwd_weight_tile_kernel(const float*
   f32x4 acc[27];
 #pragma unroll
   for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto load_x = [&](long t) {                      // this thread's x value of tile t (zeros outside)
+  // a workgroup walks a CONTIGUOUS range of tiles (x-chunk fastest, then y, z, b): the tile's
+  // coordinates advance by increments -- the strided walk spent more on 64-bit divisions than on sums
+  struct Tile { int xc, y, z, b; long row; };       // row = (b*D + z)*H + y
+  auto tile_at = [&](long t) {
+    Tile T; T.xc = (int)(t % nxc); T.row = t / nxc;
+    long r = T.row; T.y = (int)(r % H); r /= H; T.z = (int)(r % D); T.b = (int)(r / D);
+    return T;
+  };
+  auto next_tile = [&](Tile T) {
+    if (++T.xc == nxc) { T.xc = 0; ++T.row; if (++T.y == H) { T.y = 0; if (++T.z == D) { T.z = 0; ++T.b; } } }
+    return T;
+  };
+  auto load_x = [&](const Tile& T, bool live) {     // this thread's x value of the tile (zeros outside)
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t < ntile) {
-      const int xu = (int)(t % nxc) * VT + vs;
-      if (xu < W) v = *reinterpret_cast<const f32x4*>(x + ((t / nxc) * W + xu) * C + 4 * q);
-    }
+    const int xu = T.xc * VT + vs;
+    if (live && xu < W) v = *reinterpret_cast<const f32x4*>(x + (T.row * W + xu) * C + 4 * q);
     return v;
   };
-  f32x4 xnext = load_x(blockIdx.x);
-  for (long t = blockIdx.x; t < ntile; t += gridDim.x) {
-    const int xc = t % nxc; long r = t / nxc;
-    const int y = r % H; r /= H;
-    const int z = r % D; const int b = r / D;
-    const int x0 = xc * VT;
-    const f32x4 xv = xnext;
-    xnext = load_x(t + gridDim.x);                 // in flight across this tile's work
-    __syncthreads();
-    for (int i = threadIdx.x; i < 9 * (VT + 2); i += 256) {
-      const int xx = x0 - 1 + i % (VT + 2), ry = (i / (VT + 2)) % 3, rz = i / (3 * (VT + 2));
-      const int yy = y - 1 + ry, zz = z - 1 + rz;
-      gl[i] = (xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D)
-                  ? g[(((long)b * D + zz) * H + yy) * W + xx] : 0.f;
+  constexpr int NGL = (9 * (VT + 2) + 255) / 256;  // g-tile elements per thread
+  int gdx[NGL], gry[NGL], grz[NGL];                 // this thread's g-tile elements: column, row, plane offsets
+#pragma unroll
+  for (int k = 0; k < NGL; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    gdx[k] = i % (VT + 2) - 1; gry[k] = (i / (VT + 2)) % 3 - 1; grz[k] = i / (3 * (VT + 2)) - 1;
+  }
+  auto load_g = [&](const Tile& T, bool live, float (&dst)[NGL]) {
+#pragma unroll
+    for (int k = 0; k < NGL; ++k) {
+      const int xx = T.xc * VT + gdx[k], yy = T.y + gry[k], zz = T.z + grz[k];
+      float val = 0.f;
+      if (live && threadIdx.x + 256 * k < 9 * (VT + 2) && xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D)
+        val = g[(((long)T.b * D + zz) * H + yy) * W + xx];
+      dst[k] = val;
     }
+  };
+  const long t0 = ntile * blockIdx.x / gridDim.x, t1 = ntile * (blockIdx.x + 1) / gridDim.x;
+  Tile nxt = tile_at(t0);
+  f32x4 xnext = load_x(nxt, t0 < t1);
+  float gnext[NGL];
+  load_g(nxt, t0 < t1, gnext);
+  for (long t = t0; t < t1; ++t) {
+    const f32x4 xv = xnext;
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NGL; ++k)
+      if (threadIdx.x + 256 * k < 9 * (VT + 2)) gl[threadIdx.x + 256 * k] = gnext[k];
+    __syncthreads();
+    nxt = next_tile(nxt);
+    xnext = load_x(nxt, t + 1 < t1);               // both prefetches are in flight across this tile's work
+    load_g(nxt, t + 1 < t1, gnext);
     // x[u] meets g[u - tap + 1]: rows (2 - dz, 2 - dy), column vs + 2 - dx of the tile
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
@@ -806,7 +832,9 @@ extern "C" int dsm_conv3d_cout1_bwd(const void* x, const void* g, const void* w_
     if (hipMemsetAsync(dw_tapmajor, 0, (size_t)27 * C * sizeof(float), s) != hipSuccess)
       return DSM_ERR_LAUNCH;
     const long ntile32 = (long)B * D * H * dsm_cdiv(W, 32);
-    const int blocks = (int)(ntile32 < 768 ? ntile32 : 768);   // three resident per CU
+    // one workgroup per CU: the 27 C atomics each workgroup ends with all land on 27 cache lines, and with
+    // 768 workgroups they, not the sums, were the kernel's time (120 us)
+    const int blocks = (int)(ntile32 < 256 ? ntile32 : 256);
     if (C == 32 && dsm_aligned16(x))
       hipLaunchKernelGGL(cout1_bwd_weight_tile_kernel<8>, dim3(blocks), dim3(256), 0, s, (const float*)x,
                          (const float*)g, (float*)dw_tapmajor, B, D, H, W);
