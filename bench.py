@@ -44,8 +44,12 @@ H, W, MAXDISP = 384, 1280, 192
 PEAK_HBM_GBS = 8000.0
 HBM_COPY_CEILING_GBS = 6290.0      # measured float4 copy (same guide); reported beside the spec fraction
 PEAK_F32_MFMA_TFLOPS = 157.3
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense; the bf16x3 kernels issue 6 bf16 MFMAs per fp32 product
-BF16X3_MFMAS_PER_PRODUCT = 6
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 / fp16 MFMA peak
+# MFMAs a product costs on the split kernels: bf16x3 (three bf16 terms, six of nine cross terms),
+# f16x2 (two fp16 terms, three cross terms), f16 (operands rounded to fp16)
+SPLIT_MFMAS = (("bf16x3", 6, "bf16 (3-term split of fp32 operands, 6 MFMAs per product, fp32 accumulate)"),
+               ("f16x2", 3, "fp16 (2-term split of the power-of-two-scaled fp32 operands, 3 MFMAs per product, fp32 accumulate)"),
+               ("_f16_", 1, "fp16 operands (rounded), 1 MFMA per product, fp32 accumulate"))
 
 
 def synthetic_pair(seed, device):
@@ -96,15 +100,15 @@ def kernel_rooflines(summary, steps):
         per_launch = work / n
         mfma = "mfma" in name
         extra = {}
-        if mfma and "bf16x3" in name:
-            # fp32 operands split exactly into 3 bf16 terms, 6 of the 9 cross terms on the bf16
-            # MFMA, fp32 accumulate: `achieved` stays ALGORITHMIC fp32 FLOP/s, `peak` is the
-            # dense bf16 MFMA peak divided by the 6 MFMAs every product costs
+        split = next((e for e in SPLIT_MFMAS if e[0] in name), None) if mfma else None
+        if split is not None:
+            # fp32 operands on the 16-bit matrix pipe: `achieved` stays ALGORITHMIC fp32 FLOP/s,
+            # `peak` is the dense 16-bit MFMA peak divided by the MFMAs every product costs
             achieved, unit, bound = per_launch / avg_s / 1e12, "TFLOP/s", "mfma"
-            peak = round(PEAK_BF16_MFMA_TFLOPS / BF16X3_MFMAS_PER_PRODUCT, 1)
-            extra = {"mfma_dtype": "bf16 (3-term split of fp32 operands, 6 MFMAs per product, fp32 accumulate)",
-                     "bf16_mfma_tflops_executed": round(achieved * BF16X3_MFMAS_PER_PRODUCT, 1),
-                     "bf16_mfma_peak": PEAK_BF16_MFMA_TFLOPS,
+            peak = round(PEAK_BF16_MFMA_TFLOPS / split[1], 1)
+            extra = {"mfma_dtype": split[2], "mfmas_per_product": split[1],
+                     "mfma_tflops_executed": round(achieved * split[1], 1),
+                     "mfma_peak_16bit": PEAK_BF16_MFMA_TFLOPS,
                      "x_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 3)}
         elif mfma:
             achieved, peak, unit, bound = per_launch / avg_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s", "mfma"

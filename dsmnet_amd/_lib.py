@@ -17,6 +17,7 @@ DSM_F32 = 0
 DSM_NCDHW, DSM_NDHWC = 0, 1
 DSM_CONV_FP32_MFMA, DSM_CONV_COUT1_CHUNKED, DSM_CONV_TM_SHIFT, DSM_CONV_BLOCKS_SHIFT = 1, 2, 4, 16
 DSM_CONV_NO_NSPLIT = 4
+DSM_PREC_F32, DSM_PREC_F16, DSM_PREC_F16X2 = 0, 1, 2
 
 
 class Bn3dArgs(ctypes.Structure):
@@ -37,8 +38,7 @@ class Conv3dS3Args(ctypes.Structure):
                 ("Di", c_int), ("Hi", c_int), ("Wi", c_int),
                 ("Do", c_int), ("Ho", c_int), ("Wo", c_int),
                 ("Dr", c_int), ("Hr", c_int), ("Wr", c_int),
-                ("relu", c_int), ("grid", c_int), ("vol_virtual", c_int), ("vol_mask_left", c_int),
-                ("tiling", c_int)]
+                ("relu", c_int), ("grid", c_int), ("vol_virtual", c_int), ("vol_mask_left", c_int)]
 
 
 class Conv3dArgs(ctypes.Structure):
@@ -51,7 +51,7 @@ class Conv3dArgs(ctypes.Structure):
                 ("Dr", c_int), ("Hr", c_int), ("Wr", c_int),
                 ("stride", c_int), ("transposed", c_int), ("relu", c_int),
                 ("kd", c_int), ("k", c_int), ("dil", c_int), ("y_s3", c_void_p),
-                ("x_s3", c_void_p), ("flags", c_int)]
+                ("flags", c_int), ("precision", c_int), ("x_amax", c_void_p), ("y_amax", c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in dsmnet_hip.h
@@ -67,7 +67,7 @@ SIGNATURES = {
     "dsm_conv3d_packed_weight_bytes": (c_size_t, [c_int] * 3),
     "dsm_conv3d_pack_weights": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "dsm_conv_pack_weights": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
-    "dsm_conv_pack_weights_s3in": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "dsm_absmax": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "dsm_conv3d_fwd": (c_int, [ctypes.POINTER(Conv3dArgs), c_void_p]),
     "dsm_conv3d_plan": (c_int, [ctypes.POINTER(Conv3dArgs), ctypes.c_char_p, c_int]),
     "dsm_conv3d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p]),
@@ -87,7 +87,6 @@ SIGNATURES = {
     "dsm_bn3d_train_bwd": (c_int, [ctypes.POINTER(Bn3dArgs), c_void_p]),
     "dsm_decoder_cat": (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p]),
     "dsm_stage_images_nhwc16": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
-    "dsm_conv2d_first3_fwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
     "dsm_volume_relayout": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
     "dsm_conv_packed_weight_bytes": (ctypes.c_size_t, [c_int] * 4),
     "dsm_spp_branch_floats": (ctypes.c_size_t, [c_int] * 3),
@@ -132,7 +131,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.dsm_abi_version() != 5:
+    if lib.dsm_abi_version() != 6:
         raise DsmnetHipError("libdsmnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

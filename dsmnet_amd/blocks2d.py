@@ -33,31 +33,8 @@ _FUSED_TRAIN_2D_BN = _TRAIN_2D_MODE == "fused"
 _TRAIN_2D_MIN_PIXELS = int(__import__("os").environ.get("DSM_TRAIN_2D_MIN_PIXELS", 65536)) if _TRAIN_2D_MODE == "auto" else 0
 
 
-def s3in_ok(conv):
-    """Can ``conv``'s kernel read its input in the S3 format (costvolume.S3Volume)?"""
-    if not (cv.get_option("s3") and cv.get_option("s3in") and isinstance(conv, nn.Conv2d)):
-        return False
-    k, s, d, p = conv.kernel_size, conv.stride, conv.dilation, conv.padding
-    if k[0] != k[1] or s[0] != s[1] or d[0] != d[1] or p[0] != p[1] or conv.groups != 1:
-        return False
-    if p[0] != d[0] * (k[0] - 1) // 2 or conv.padding_mode != "zeros":
-        return False
-    return cv.conv_s3in_eligible(conv.in_channels, conv.out_channels, s[0], False, kd=1, k=k[0], dil=d[0])
-
-
-def s3out_ok(conv):
-    """Does ``conv``'s kernel have the S3 epilogue (the bf16x3 kernels: 3x3, stride 1)?"""
-    if not (cv.get_option("s3") and isinstance(conv, nn.Conv2d) and cv.get_option_bf16x3()):
-        return False
-    return (conv.kernel_size[0] == 3 and conv.stride[0] == 1 and conv.out_channels % 32 == 0 and
-            conv.out_channels <= 128 and conv.in_channels % 16 == 0 and
-            (conv.dilation[0] == 1 or conv.out_channels == 128))
-
-
 def fused_ok(conv, x):
     """Can ``conv`` (an nn.Conv2d) run on the MFMA kernel for input ``x``?"""
-    if isinstance(x, cv.S3Volume):
-        return s3in_ok(conv) and x.shape[1] == conv.in_channels
     if not (isinstance(conv, nn.Conv2d) and x.is_cuda and x.dtype == torch.float32):
         return False
     k, s, d, p = conv.kernel_size, conv.stride, conv.dilation, conv.padding
@@ -82,15 +59,6 @@ class _Folded2d(object):
     def __init__(self):
         self.key = None
         self.packed = self.scale = self.shift = None
-        self.packed_s3in = None
-
-    def get_s3in(self, conv, bn):
-        """(weights packed for a launch that reads an S3 input, scale, shift)."""
-        _, scale, shift = self.get(conv, bn, conv.in_channels)
-        if self.packed_s3in is None:
-            with torch.no_grad():
-                self.packed_s3in = cv.pack_conv_weight_s3in(conv.weight)
-        return self.packed_s3in, scale, shift
 
     def get(self, conv, bn, cin_padded):
         srcs = [conv.weight, conv.bias]
@@ -115,7 +83,6 @@ class _Folded2d(object):
                 else:
                     self.scale = self.shift = None
             self.key = key
-            self.packed_s3in = None
         return self.packed, self.scale, self.shift
 
 
@@ -159,20 +126,14 @@ def _run_conv2d_autograd(conv, bn, x, residual, relu):
     return F.relu(y) if relu else y
 
 
-def run_conv2d(folded, conv, bn, x, residual=None, relu=False, out="f32"):
-    """conv (+BN) (+skip) (+ReLU): fused when possible, stock torch otherwise.  ``x``: a tensor or
-    (eval) the map as an ``S3Volume``; ``out``: "f32" | "s3" | "both" (eval, bf16x3 layers)."""
+def run_conv2d(folded, conv, bn, x, residual=None, relu=False):
+    """conv (+BN) (+skip) (+ReLU): fused when possible, stock torch otherwise."""
     training = bn is not None and bn.training
     if not training and not torch.is_grad_enabled() and fused_ok(conv, x):
-        if isinstance(x, cv.S3Volume):
-            packed, scale, shift = folded.get_s3in(conv, bn)
-        else:
-            packed, scale, shift = folded.get(conv, bn, x.shape[1])
+        packed, scale, shift = folded.get(conv, bn, x.shape[1])
         return cv.conv2d_block(x, packed, conv.out_channels, scale, shift, residual,
                                stride=conv.stride[0], relu=1 if relu else 0,
-                               k=conv.kernel_size[0], dilation=conv.dilation[0], out=out)
-    if isinstance(x, cv.S3Volume) or out != "f32":
-        raise RuntimeError("S3 activations exist on the fused eval path only")
+                               k=conv.kernel_size[0], dilation=conv.dilation[0])
     if train_ok(conv, x):
         return _run_conv2d_autograd(conv, bn, x, residual, relu)
     if x.shape[1] != conv.in_channels:            # zero-padded staging channels
@@ -192,8 +153,8 @@ class ConvBN2d(nn.Sequential):
         super(ConvBN2d, self).__init__(conv, bn)
         self._folded = _Folded2d()
 
-    def forward(self, x, residual=None, relu=False, out="f32"):
-        return run_conv2d(self._folded, self[0], self[1], x, residual, relu, out)
+    def forward(self, x, residual=None, relu=False):
+        return run_conv2d(self._folded, self[0], self[1], x, residual, relu)
 
 
 def stage_image_nhwc16(img):

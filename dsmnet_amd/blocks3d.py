@@ -44,7 +44,6 @@ class _Folded(object):
         self.key = None
         self.packed = self.scale = self.shift = None
         self.packed_s3 = None            # packing for the z-sliding S3 kernel, made on first use
-        self.packed_s3in = None          # packing for a bf16x3 launch that reads an S3 input
 
     def get(self, conv, bn):
         transposed = isinstance(conv, nn.ConvTranspose3d)
@@ -71,16 +70,8 @@ class _Folded(object):
                 else:
                     self.scale = self.shift = None
             self.key = key
-            self.packed_s3 = self.packed_s3in = None
+            self.packed_s3 = None
         return self.packed, self.scale, self.shift
-
-    def get_s3in(self, conv, bn):
-        """(weights packed for a bf16x3 launch with an S3 input, scale, shift)."""
-        _, scale, shift = self.get(conv, bn)
-        if self.packed_s3in is None:
-            with torch.no_grad():
-                self.packed_s3in = cv.pack_conv_weight_s3in(conv.weight)
-        return self.packed_s3in, scale, shift
 
     def get_s3(self, conv, bn):
         """(weights packed for ``conv3d_s3_block``, scale, shift)."""
@@ -148,15 +139,9 @@ def _s3_layer(conv):
             cv.conv3d_s3_eligible(conv.in_channels, conv.out_channels, conv.stride[0], False))
 
 
-def _s3in_layer(conv):
-    """Can this layer's bf16x3 kernel read an S3 input?"""
-    return (cv.get_option("s3") and cv.get_option("s3in") and isinstance(conv, nn.Conv3d) and
-            cv.conv_s3in_eligible(conv.in_channels, conv.out_channels, conv.stride[0], False))
-
-
 def takes_s3(conv):
-    """An S3 input is worth making for this layer (either S3 path applies)."""
-    return _s3_layer(conv) or _s3in_layer(conv)
+    """An S3 input is worth making for this layer."""
+    return _s3_layer(conv)
 
 
 def _fast_eval(conv, bn, x):
@@ -196,10 +181,6 @@ def run_block(folded, conv, bn, x, residual=None, relu=RELU_NONE, out="f32"):
         if _s3_layer(conv):
             packed, scale, shift = folded.get_s3(conv, bn)
             return cv.conv3d_s3_block(x, packed, scale, shift, residual, relu=relu, out=out)
-        if _s3in_layer(conv) and x.features is None:
-            packed, scale, shift = folded.get_s3in(conv, bn)
-            return cv.conv3d_block(x, packed, conv.out_channels, scale, shift, residual,
-                                   stride=conv.stride[0], transposed=False, relu=relu, out=out)
         x = x.to_tensor()                      # a consumer without an S3 path (not a reference pattern)
     packed, scale, shift = folded.get(conv, bn)
     if out != "f32" and not cv.conv3d_supports_s3_out(conv.in_channels, conv.out_channels,

@@ -214,7 +214,11 @@ def concat_volume(fL, fR, D, mask_left, channels_last=True):
     ``mask_left=False``: GCNet (gcnet.py:130-135); ``True``: PSMNet
     (stackhourglass.py:124-133).  ``channels_last`` selects the memory format of the
     result: ``torch.channels_last_3d`` (what ``conv3d_block`` consumes) or contiguous."""
-    return ConcatVolumeFunction.apply(fL, fR, int(D), bool(mask_left), bool(channels_last))
+    vol = ConcatVolumeFunction.apply(fL, fR, int(D), bool(mask_left), bool(channels_last))
+    sl = getattr(fL, "_dsm_amax", None)
+    if sl is not None and sl is getattr(fR, "_dsm_amax", None):
+        vol._dsm_amax = sl                  # copies of the features: the same bound holds
+    return vol
 
 
 # ----------------------------------------------------------------------------
@@ -331,13 +335,10 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     the result is returned as a channels_last_3d tensor.  With ``residual`` the output
     takes the element-wise minimum of the two spatial sizes -- ``myadd_3d`` semantics
     (stackhourglass.py:10-20).  ``out``: "f32" -> tensor; "s3" / "both" -> the result (also) as an
-    S3Volume for a following ``conv3d_s3_block`` (bf16x3 kernels only).  Inference only."""
-    xs3 = x if isinstance(x, S3Volume) else None
-    _require_device("conv3d_block", None if xs3 else x, scale, shift, residual)
-    if xs3 is None:
-        x = to_channels_last_3d(x)
-    elif xs3.features is not None:
-        raise ValueError("conv3d_block cannot read a virtual cost volume")
+    S3Volume for a following ``conv3d_s3_block`` (bf16x3 kernels only).  Inference only.
+    What the MFMA kernels multiply in follows the ``conv_precision`` option (``set_option``)."""
+    _require_device("conv3d_block", x, scale, shift, residual)
+    x = to_channels_last_3d(x)
     B, cin, Di, Hi, Wi = x.shape
     Do, Ho, Wo = conv3d_out_size((Di, Hi, Wi), stride, transposed)
     a = _lib.Conv3dArgs()
@@ -356,10 +357,7 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
         y = torch.empty(oshape, device=x.device, dtype=torch.float32, memory_format=_CL3D)
     if out in ("s3", "both"):
         ys3 = S3Volume(_s3_alloc(oshape, x.device), oshape)
-    if xs3 is None:
-        a.x = x.data_ptr()
-    else:
-        a.x_s3 = xs3.buf.data_ptr()           # packed_weight must come from pack_conv_weight_s3in
+    a.x = x.data_ptr()
     a.w_packed = packed_weight.data_ptr()
     a.y = None if y is None else y.data_ptr()
     a.y_s3 = None if ys3 is None else ys3.buf.data_ptr()
@@ -371,6 +369,7 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     a.Do, a.Ho, a.Wo = Do, Ho, Wo
     a.stride, a.transposed, a.relu = int(stride), int(transposed), int(relu)
     a.flags = _conv_flags()
+    keep = _set_precision(a, x, y if cout > 1 else None)
     # FLOPs as SURVEY.md section 8d counts them: 2*27*Cin*Cout per output voxel (conv) or
     # per input voxel (transposed conv)
     # (Cout = 1 runs on the VALU and is HBM-bound: input read once + output written)
@@ -379,6 +378,7 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     with torch.cuda.device(x.device), _timed(lambda: conv3d_plan_name(a), work):
         rc = _lib.load().dsm_conv3d_fwd(ctypes.byref(a), _stream())
     _lib.check(rc, "dsm_conv3d_fwd")
+    del keep
     if out == "f32":
         return y
     if out == "s3":
@@ -396,39 +396,8 @@ def conv3d_supports_s3_out(cin, cout, stride, transposed):
 
 
 def get_option_bf16x3():
-    return not _OPTIONS["conv_fp32"]
-
-
-def conv_s3in_eligible(cin, cout, stride, transposed, kd=3, k=3, dil=1):
-    """Layers whose bf16x3 convolution kernel can read an S3 input (conv3d.hip make_plan +
-    the variants compiled there): 3x3(x3), not transposed, Cin % 32 == 0."""
-    if transposed or k != 3 or cin % 32 != 0 or not get_option_bf16x3():
-        return False
-    return _conv_s3in_compiled(cout, stride, kd, dil)
-
-
-def _conv_s3in_compiled(cout, stride, kd, dil):
-    if kd == 3:
-        return dil == 1 and ((stride == 1 and cout in (32, 64)) or (stride == 2 and cout == 64))
-    return stride == 1 and ((dil == 1 and cout in (32, 64, 128)) or (dil == 2 and cout == 128))
-
-
-def pack_conv_weight_s3in(weight):
-    """torch Conv3d / Conv2d weight (k = 3) -> the packed buffer of a launch that reads an S3 input
-    (the bf16x3 section in the k-slot order of the S3 units)."""
-    _require_device("pack_conv_weight_s3in", weight)
-    kd = 3 if weight.dim() == 5 else 1
-    cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[-1]
-    w = weight.detach().contiguous()
-    lib = _lib.load()
-    nbytes = lib.dsm_conv_packed_weight_bytes(cin, cout, kd, k)
-    if nbytes == 0:
-        raise ValueError("pack_conv_weight_s3in: unsupported shape %s" % (tuple(weight.shape),))
-    packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
-    with torch.cuda.device(w.device):
-        rc = lib.dsm_conv_pack_weights_s3in(_p(w), _p(packed), cin, cout, kd, k, _stream())
-    _lib.check(rc, "dsm_conv_pack_weights_s3in")
-    return packed
+    """The split kernels run in their bf16x3 form (the only one with the S3 hand-over format)."""
+    return _OPTIONS["conv_precision"] == "bf16x3"
 
 
 def conv3d_plan_name(args):
@@ -445,45 +414,182 @@ def conv3d_plan_name(args):
 import os as _os
 
 # host-side options (the library itself reads no environment variable): "conv_precision" starts from
-# DSM_CONV_PRECISION=fp32|bf16x3 so that scripts and the parity tests can switch whole runs
-_OPTIONS = {"s3": True, "fuse_volume": True, "s3in": False,
-            "conv_fp32": _os.environ.get("DSM_CONV_PRECISION", "").startswith("f"),
-            "conv_flags": 0, "s3_tiling": 0, "overlap_heads": False, "first3": False}
+# DSM_CONV_PRECISION=bf16x3|fp32|f16x2|f16 so that scripts and the parity tests can switch whole runs
+_PRECISIONS = ("bf16x3", "fp32", "f16x2", "f16")
+
+
+def _env_precision():
+    v = _os.environ.get("DSM_CONV_PRECISION", "")
+    if v and v not in _PRECISIONS:
+        raise ValueError("DSM_CONV_PRECISION must be one of %s, got %r" % (_PRECISIONS, v))
+    return v or "bf16x3"
+
+
+_OPTIONS = {"s3": True, "fuse_volume": True, "conv_precision": _env_precision(), "conv_flags": 0}
 
 
 def set_option(name, value):
     """Host-side switches for A/B runs and tests (no environment variable is read by the library):
-    ``s3`` -- eval-mode 32-channel stride-1 3-D layers run on the z-sliding S3 kernel;
-    ``fuse_volume`` -- PSMNet's eval forward never materialises the cost volume: the first 3-D
-    convolution stages it from the split feature maps;
-    ``s3in`` -- the OTHER bf16x3 convolutions (2-D towers, stride-2 and 64-channel 3-D layers) also
-    take their input pre-split.  Off by default: measured in one process on the PSMNet forward
-    (scripts/ab_paths.py, r02) it LOSES 4-17 % on every one of those kernels -- their operand
-    split already rides in the shadow of the 32-cycle 32x32x16 MFMAs, while an S3 input costs 50 %
-    more staged bytes and its producer an epilogue split.
-    ``s3_tiling`` -- dsm_conv3d_s3_args.tiling of every S3 convolution launch (0 = the library's
-    default, 1 = 8 x 32 tile / one workgroup per CU, 2 = 4 x 32 tile / two per CU);
-    ``first3`` -- PSMNet's first tower layer (3 -> 32, stride 2) runs on the VALU kernel straight from
-    the raw images instead of NHWC staging + the MFMA kernel (off: 55 us against 15 + 37 us, no gain
-    inside the forward -- profiles/r02_ablation.md section 6);
-    ``overlap_heads`` -- PSMNet's eval forward runs classif1/classif2 and their soft-argmin heads on a
-    second HIP stream beside the next hourglass (fork / join with events; a hipGraph captures both
-    branches)."""
+    ``conv_precision`` -- what the 3x3(x3) MFMA convolutions multiply in:
+        "bf16x3"  fp32 accuracy, three-term bf16 split, six MFMAs per product (DESIGN.md 3.2a);
+        "f16x2"   fp32 accuracy, two-term fp16 split of power-of-two-scaled operands, three MFMAs;
+        "f16"     operands rounded to fp16, one MFMA, fp32 accumulate -- the reduced-precision mode of
+                  BASELINE config #5 (forward, backward-data and weight gradients);
+        "fp32"    the exact fp32-input MFMA (v_mfma_f32_32x32x2_f32);
+    ``conv_fp32`` -- older spelling: True = "fp32", False = "bf16x3";
+    ``s3`` -- bf16x3 only: eval-mode 32-channel stride-1 3-D layers run on the z-sliding S3 kernel;
+    ``fuse_volume`` -- PSMNet's / GCNet's eval forward never materialises the cost volume: the first
+    3-D convolution stages it from the feature maps;
+    ``conv_flags`` -- raw dsm_conv3d_args.flags bits (tile height, grid size)."""
+    if name == "conv_fp32":
+        old = _OPTIONS["conv_precision"] == "fp32"
+        _OPTIONS["conv_precision"] = "fp32" if value else "bf16x3"
+        return old
     if name not in _OPTIONS:
         raise KeyError(name)
     old = _OPTIONS[name]
-    _OPTIONS[name] = int(value) if name in ("conv_flags", "s3_tiling") else bool(value)
+    if name == "conv_precision":
+        if value not in _PRECISIONS:
+            raise ValueError("conv_precision must be one of %s" % (_PRECISIONS,))
+        _OPTIONS[name] = value
+    else:
+        _OPTIONS[name] = int(value) if name == "conv_flags" else bool(value)
     return old
 
 
 def _conv_flags():
-    """dsm_conv3d_args.flags of every convolution launch: ``conv_fp32`` keeps the exact fp32-input
+    """dsm_conv3d_args.flags of every convolution launch: precision "fp32" keeps the exact fp32-input
     MFMA kernels; ``conv_flags`` carries raw A/B bits (tile height, grid size: include/dsmnet_hip.h)."""
-    return (_lib.DSM_CONV_FP32_MFMA if _OPTIONS["conv_fp32"] else 0) | _OPTIONS["conv_flags"]
+    return (_lib.DSM_CONV_FP32_MFMA if _OPTIONS["conv_precision"] == "fp32" else 0) | _OPTIONS["conv_flags"]
 
 
 def get_option(name):
+    if name == "conv_fp32":
+        return _OPTIONS["conv_precision"] == "fp32"
     return _OPTIONS[name]
+
+
+# ----------------------------------------------------------------------------
+# absolute maxima for the fp16 precisions (include/dsmnet_hip.h: x_amax / y_amax)
+# ----------------------------------------------------------------------------
+# The fp16 split kernels scale every tensor by a power of two taken from its absolute maximum -- a
+# device float that the PRODUCING launch writes from its epilogue (atomic max) and the consumer
+# reads at kernel start: no host round trip, capturable in a hipGraph.  On the host the scalar rides
+# on the tensor object as ``_dsm_amax``; a tensor without one (an input of the model, the result of
+# a stock torch op) gets it from one ``dsm_absmax`` pass.  Slots come from a per-device arena that a
+# model forward zeroes once (``amax_scope``), so that a forward costs one fill, not one per layer.
+class _AmaxArena(object):
+    SLOTS = 2048
+
+    def __init__(self):
+        self.buf, self.used, self.depth = {}, {}, 0
+
+    def begin(self, device):
+        key = (device.type, device.index)
+        if key not in self.buf:
+            self.buf[key] = torch.zeros(self.SLOTS, device=device, dtype=torch.float32)
+        else:
+            self.buf[key].zero_()
+        self.used[key] = 0
+
+    def slot(self, device):
+        key = (device.type, device.index)
+        if self.depth > 0 and key in self.buf and self.used[key] < self.SLOTS:
+            i = self.used[key]
+            self.used[key] = i + 1
+            return self.buf[key][i:i + 1]
+        return torch.zeros(1, device=device, dtype=torch.float32)
+
+
+_ARENA = _AmaxArena()
+
+
+class amax_scope(object):
+    """``with amax_scope(device):`` around a model forward: the absolute-maximum slots of every
+    launch inside come from one arena, zeroed once on entry (nested scopes share the outer one).
+    A no-op unless an fp16 precision is selected."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        if needs_amax():
+            if _ARENA.depth == 0:
+                _ARENA.begin(self.device)
+            _ARENA.depth += 1
+            self.entered = True
+        else:
+            self.entered = False
+        return self
+
+    def __exit__(self, *exc):
+        if self.entered:
+            _ARENA.depth -= 1
+        return False
+
+
+def needs_amax():
+    return _OPTIONS["conv_precision"] in ("f16x2", "f16")
+
+
+def absmax(x):
+    """Device scalar holding max |x| (one pass, ``dsm_absmax``), also remembered on ``x``."""
+    slot = _ARENA.slot(x.device)
+    with torch.cuda.device(x.device), _timed("absmax_kernel", 4.0 * x.numel()):
+        rc = _lib.load().dsm_absmax(_p(x), x.numel(), _p(slot), _stream())
+    _lib.check(rc, "dsm_absmax")
+    try:
+        x._dsm_amax = slot
+    except AttributeError:
+        pass
+    return slot
+
+
+def amax_of(x):
+    """The absolute-maximum scalar of ``x``: the one its producer attached, else a fresh pass."""
+    slot = getattr(x, "_dsm_amax", None)
+    return slot if slot is not None else absmax(x)
+
+
+def carry_amax(dst, *srcs):
+    """``dst`` holds values bounded by the maximum over ``srcs`` (a view, a slice, a concatenation):
+    hand the bound on without a pass when a single source carries one."""
+    slots = [getattr(t, "_dsm_amax", None) for t in srcs]
+    if len(slots) == 1 and slots[0] is not None:
+        dst._dsm_amax = slots[0]
+    return dst
+
+
+def _split_kernel_layer(a):
+    """Does ``dsm_conv3d_fwd`` run this layer on a split-operand kernel (conv3d.hip make_plan kinds
+    5 / 6)?  3x3(x3) taps, Cin % 16 == 0, Cout a multiple of 32 up to 64 (3-D) / 128 (2-D); stride 1,
+    3-D stride 2 to 64 channels, or transposed from Cin % 32 == 0."""
+    kd, k = (a.kd or 3), (a.k or 3)
+    if k != 3 or a.Cin % 16 or a.Cout % 32 or a.Cout > (64 if kd == 3 else 128):
+        return False
+    if a.transposed:
+        return kd == 3 and a.Cin % 32 == 0
+    return a.stride == 1 or (kd == 3 and a.Cout == 64)
+
+
+def _set_precision(a, x, y):
+    """precision / x_amax / y_amax of a ``dsm_conv3d_args``.  Returns the tensors the launch must
+    keep alive.  ``x``, ``y``: the input and output tensors (NDHWC / NHWC memory); ``y`` None:
+    the output needs no maximum (Cout = 1 heads)."""
+    mode = _OPTIONS["conv_precision"]
+    if mode not in ("f16x2", "f16"):
+        return None
+    a.precision = _lib.DSM_PREC_F16X2 if mode == "f16x2" else _lib.DSM_PREC_F16
+    xa = None
+    if _split_kernel_layer(a):                       # the others compute in fp32 and read no maximum
+        xa = amax_of(x)
+        a.x_amax = xa.data_ptr()
+    ya = None
+    if y is not None:
+        ya = _ARENA.slot(y.device)
+        a.y_amax = ya.data_ptr()
+        y._dsm_amax = ya
+    return xa, ya
 
 
 class S3Volume(object):
@@ -614,7 +720,6 @@ def conv3d_s3_block(x, packed_weight, scale=None, shift=None, residual=None, rel
     a.Di, a.Hi, a.Wi = Di, Hi, Wi
     a.Do, a.Ho, a.Wo = Do, Ho, Wo
     a.relu, a.grid = int(relu), int(grid)
-    a.tiling = int(_OPTIONS["s3_tiling"])
     if x.features is not None:
         a.vol_virtual, a.vol_mask_left = 1, x.features[1]
     work = 54.0 * cin * 32 * B * Do * Ho * Wo
@@ -657,17 +762,12 @@ def pack_conv2d_weight(weight, cin_padded=None):
 def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, stride=1,
                  relu=0, k=3, dilation=1, out="f32"):
     """y = relu?(conv2d(x) * scale + shift (+ residual)) on NHWC maps, "same" padding.
-    ``x``: (B, Cin, H, W) in torch.channels_last memory, Cin a multiple of 16 -- or the map as an
-    ``S3Volume`` of shape (B, Cin, 1, H, W) (weights then from ``pack_conv_weight_s3in``).
+    ``x``: (B, Cin, H, W) in torch.channels_last memory, Cin a multiple of 16.
     ``out``: "f32" -> tensor; "s3" / "both" -> (also) an S3Volume (bf16x3 kernels).  Inference only."""
-    xs3 = x if isinstance(x, S3Volume) else None
-    _require_device("conv2d_block", None if xs3 else x, packed_weight, scale, shift, residual)
-    if xs3 is None:
-        if not x.is_contiguous(memory_format=_CL2D):
-            x = x.contiguous(memory_format=_CL2D)
-        B, cin, Hi, Wi = x.shape
-    else:
-        B, cin, _, Hi, Wi = xs3.shape
+    _require_device("conv2d_block", x, packed_weight, scale, shift, residual)
+    if not x.is_contiguous(memory_format=_CL2D):
+        x = carry_amax(x.contiguous(memory_format=_CL2D), x)
+    B, cin, Hi, Wi = x.shape
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
     a = _lib.Conv3dArgs()
     if residual is not None:
@@ -683,10 +783,7 @@ def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
         y = torch.empty((B, cout, Ho, Wo), device=dev, dtype=torch.float32, memory_format=_CL2D)
     if out in ("s3", "both"):
         ys3 = S3Volume(_s3_alloc((B, cout, 1, Ho, Wo), dev), (B, cout, 1, Ho, Wo))
-    if xs3 is None:
-        a.x = x.data_ptr()
-    else:
-        a.x_s3 = xs3.buf.data_ptr()
+    a.x = x.data_ptr()
     a.w_packed = packed_weight.data_ptr()
     a.y = None if y is None else y.data_ptr()
     a.y_s3 = None if ys3 is None else ys3.buf.data_ptr()
@@ -699,10 +796,12 @@ def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     a.stride, a.transposed, a.relu = int(stride), 0, int(relu)
     a.kd, a.k, a.dil = 1, int(k), int(dilation)
     a.flags = _conv_flags()
+    keep = _set_precision(a, x, y)
     work = 2.0 * k * k * cin * cout * B * Ho * Wo
     with torch.cuda.device(dev), _timed(lambda: conv3d_plan_name(a), work):
         rc = _lib.load().dsm_conv3d_fwd(ctypes.byref(a), _stream())
     _lib.check(rc, "dsm_conv3d_fwd")
+    del keep
     if out == "f32":
         return y
     if out == "s3":
@@ -965,29 +1064,6 @@ def stage_images_nhwc16(left, right=None):
     with torch.cuda.device(left.device):
         rc = _lib.load().dsm_stage_images_nhwc16(_p(left), _p(right), _p(out), B, C, H, W, _stream())
     _lib.check(rc, "dsm_stage_images_nhwc16")
-    return out
-
-
-def conv2d_first3(left, right, w_taps, scale=None, shift=None, relu=True):
-    """PSMNet's first tower layer straight from the raw NCHW images: Conv2d(3 -> 32, k3, s2, p1) with
-    the folded BN affine and ReLU, both views in one launch -> (2B or B, 32, H/2, W/2) channels_last.
-    ``w_taps``: the (32,3,3,3) weight as a contiguous (27, 32) tap-major tensor.  Inference only."""
-    _require_device("conv2d_first3", left, right, w_taps, scale, shift)
-    left = left.contiguous()
-    B, C, H, W = left.shape
-    if C != 3 or tuple(w_taps.shape) != (27, 32):
-        raise ValueError("conv2d_first3: a 3-channel image and (27, 32) tap-major weights are expected")
-    if right is not None:
-        if tuple(right.shape) != tuple(left.shape):
-            raise ValueError("conv2d_first3: the two views differ in shape")
-        right = right.contiguous()
-    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    out = torch.empty(((1 if right is None else 2) * B, 32, Ho, Wo), device=left.device,
-                      dtype=torch.float32, memory_format=_CL2D)
-    with torch.cuda.device(left.device), _timed("conv2d_first3_kernel", 2.0 * 27 * 32 * out.shape[0] * Ho * Wo):
-        rc = _lib.load().dsm_conv2d_first3_fwd(_p(left), _p(right), _p(w_taps), _p(scale), _p(shift),
-                                               _p(out), B, H, W, int(bool(relu)), _stream())
-    _lib.check(rc, "dsm_conv2d_first3_fwd")
     return out
 
 

@@ -34,8 +34,7 @@
 //
 // K order inside an 8-channel group: MFMA step j multiplies channels
 // {8g + j (lanes 0-31), 8g + 4 + j (lanes 32-63)}; A and B fragments agree on it.
-#include "common.hpp"
-#include <type_traits>
+#include "conv_common.hpp"
 
 #ifdef DSM_STAMPS
 // Diagnostic build only (python dsmnet_amd/csrc/build.py --stamps): per-phase cycle totals of
@@ -68,191 +67,6 @@ extern "C" int dsm_debug_read_stamps(unsigned long long* host, int zero) {
 
 namespace {
 
-// Compile-time loop: f(integral_constant<int, I>) for I in [I0, N).  Used where an index must
-// be a constant expression so that accumulator arrays stay in registers (a runtime-indexed
-// ext-vector array goes to scratch).
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-constexpr int NTHREADS = 256;
-
-// Input-tile geometry for an output tile of TY rows x 32 columns, one z.
-// KZ x KXY x KXY taps (KZ = 1: a 2-D convolution on (B,1,H,W,C) volumes), dilation DIL in
-// (y, x), padding = "same" ((K-1)/2 * dilation), stride S.
-template <int S, int KZ = 3, int KXY = 3, int DIL = 1> struct Geo {
-  static constexpr int IZ = KZ;
-  static constexpr int EXT = (KXY - 1) * DIL;           // halo span in y and x
-  static constexpr int PADZ = (KZ - 1) / 2, PADXY = EXT / 2;
-  static constexpr int NTAP = KZ * KXY * KXY;
-  static __host__ __device__ constexpr int IY(int TY) { return (TY - 1) * S + EXT + 1; }
-  static constexpr int IX = 31 * S + EXT + 1;           // 34 or 65 for the 3x3x3 trunk
-  static constexpr int XE = (IX + 1) / 2;               // even columns when S == 2
-  static constexpr int XP = (S == 1) ? IX : 2 * XE;     // LDS row pitch in 16-B elements
-  static __host__ __device__ constexpr int xmap(int x) {
-    return S == 1 ? x : ((x & 1) * XE + (x >> 1));
-  }
-};
-
-struct ConvParams {
-  const float* x; const float* w; const float* scale; const float* shift;
-  const float* res; float* y;
-  unsigned char* ys3;         // optional second output in the S3 format (conv_s3.hip); bf16x3 kernels only
-  int force_blocks;           // 0, or the persistent grid size asked for in dsm_conv3d_args.flags
-  int B, Cin, Cout;
-  int Di, Hi, Wi, Do, Ho, Wo, Dr, Hr, Wr;
-  int relu;
-  int ntx, nty, ntiles;       // tile grid: x tiles, y tiles, total = B*Do*nty*ntx (x8 classes for deconv)
-  unsigned xbytes, wbytes;    // extents of x and w for the buffer descriptors (< 4 GiB)
-  int ntp;                    // Cout / 32 of the layer (packing and output stride); a launch may
-                              // compute only NT of them per workgroup column (blockIdx.y: N-split)
-};
-
-// XCD-aware persistent tile order: workgroups are dealt round-robin over the 8
-// XCDs, so worker (xcd = id % 8, slot = id / 8) walks a contiguous eighth of the
-// tile space -- neighbouring tiles (shared halos) meet in one XCD's L2.  Speed only.
-__device__ __forceinline__ int first_tile(int ntiles, int& step, int& end) {
-  const int id = blockIdx.x, G = gridDim.x;
-  if ((G & 7) != 0 || ntiles < 64) { step = G; end = ntiles; return id; }
-  const int xcd = id & 7, slot = id >> 3;
-  const int per = (ntiles + 7) >> 3;
-  const int lo = xcd * per;
-  end = min(ntiles, lo + per);
-  step = G >> 3;
-  return lo + slot;
-}
-
-// Epilogue of one 32x32 accumulator tile.  The MFMAs are issued with the WEIGHT fragment as
-// the A operand and the activation fragment as B, so the tile comes out transposed: lane
-// (r = lane & 31, h = lane >> 5) owns output voxel r of the row and register k holds channel
-// (k & 3) + 8 (k >> 2) + 4 h -- four consecutive channels per register quad, i.e. 16
-// contiguous bytes of the NDHWC voxel.  Each lane therefore issues 4 dwordx4 stores (and 4
-// dwordx4 skip loads) per tile instead of 16 dword ones: the store tail is issue-bound, not
-// bandwidth-bound (measured: ~20k cycles per tile with dword stores).
-//   y = acc*scale + shift (ReLU?) (+ skip) (ReLU?)
-// `yv` / `rv` point at this lane's voxel, channel 32*n + 4*h; XS = voxel stride between
-// consecutive lanes (1, or 2 for a transposed-conv parity class).
-// per-lane epilogue constants: scale/shift of the 16 channels this lane owns in one N-tile
-struct Affine { f32x4 sc[4], sh[4]; };
-__device__ __forceinline__ Affine load_affine(const float* __restrict__ scale,
-                                              const float* __restrict__ shift, int cbase) {
-  Affine a;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
-    a.sc[g] = scale ? *reinterpret_cast<const f32x4*>(scale + cbase + 8 * g) : one;
-    a.sh[g] = shift ? *reinterpret_cast<const f32x4*>(shift + cbase + 8 * g) : zero;
-  }
-  return a;
-}
-
-template <int COUT>
-__device__ __forceinline__ void store_tile(const f32x16& acc, const Affine& af, int relu,
-                                           float* __restrict__ yv, const float* __restrict__ rv) {
-  f32x4 r4[4];
-  if (rv) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) r4[g] = *reinterpret_cast<const f32x4*>(rv + 8 * g);
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const f32x4 sc = af.sc[g], sh = af.sh[g];
-    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-    v = v * sc + sh;
-    if (relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (rv) v += r4[g];
-    if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    *reinterpret_cast<f32x4*>(yv + 8 * g) = v;
-  }
-}
-
-// The same epilogue, the result also (or only) written in the S3 format of conv_s3.hip -- fp32
-// pre-split into three bf16 planes, [..][y][cg][plane][g][x][8] -- so that a z-sliding bf16x3
-// consumer needs no operand split.  Lane (r, h) of a 32x32 tile owns channels 8 q + 4 h + (0..3)
-// of its voxel (register quads q = 0..3), i.e. exactly the units g = h (quads 0, 2) and g = 2 + h
-// (quads 1, 3) of the voxel's 32-channel group: two 16-byte stores per plane.
-// `s3row`: the (voxel row, channel group) row-set, 12 rows of `Wo` units; `xo`: this lane's column.
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned s3_pack_bf16(float a, float b) {
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-  const f2 t = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(t, b2));
-}
-__device__ __forceinline__ void s3_store_unit(const f32x4 lo4, const f32x4 hi4, unsigned char* o, long plane_stride) {
-  float r[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    unsigned u[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      u[i] = s3_pack_bf16(r[2 * i], r[2 * i + 1]);
-      if (k < 2) {
-        r[2 * i] -= __builtin_bit_cast(float, u[i] << 16);
-        r[2 * i + 1] -= __builtin_bit_cast(float, u[i] & 0xffff0000u);
-      }
-    }
-    *reinterpret_cast<u32x4_t*>(o + k * plane_stride) = u32x4_t{u[0], u[1], u[2], u[3]};
-  }
-}
-template <int COUT>
-__device__ __forceinline__ void store_tile_s3(const f32x16& acc, const Affine& af, int relu,
-                                              float* __restrict__ yv, const float* __restrict__ rv,
-                                              unsigned char* __restrict__ s3row, int xo, int Wo, int h) {
-  f32x4 r4[4], v4[4];
-  if (rv) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) r4[g] = *reinterpret_cast<const f32x4*>(rv + 8 * g);
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const f32x4 sc = af.sc[g], sh = af.sh[g];
-    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-    v = v * sc + sh;
-    if (relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (rv) v += r4[g];
-    if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (yv) *reinterpret_cast<f32x4*>(yv + 8 * g) = v;
-    v4[g] = v;
-  }
-  const long ps = 4l * Wo * 16;
-  s3_store_unit(v4[0], v4[2], s3row + ((long)h * Wo + xo) * 16, ps);
-  s3_store_unit(v4[1], v4[3], s3row + ((long)(2 + h) * Wo + xo) * 16, ps);
-}
-
-// ----------------------------------------------------------------------------
-// Staging of one channel chunk of a halo tile: global -> registers -> LDS.
-//
-// On gfx950 the fp32 MFMA shares the SIMD's vector ALU ("runs at the vector rate"): every
-// VALU instruction of either resident wave is time taken from the matrix pipe (stamps: two
-// workgroups per CU spend 2 x 27.6k cycles in MFMAs + 2 x 6.6k in VALU per pair of chunks,
-// and staging code that runs 3k cycles alone takes 14k beside a multiplying partner).  So
-// the staging path is built to issue (almost) no VALU:
-//  * the LDS image is stored in element order e = ((z*IY + y)*IX + x)*NQ + q and thread
-//    `tid` owns elements e = tid + 256*k: a commit is NPF ds_write_b128 with immediate
-//    offsets (the A-fragment reads then have a 4-way bank conflict, irrelevant beside
-//    64-cycle MFMAs);
-//  * each thread's global offsets are computed once per launch; a chunk whose halo box lies
-//    inside the volume (wave-uniform test) is staged by loads of the form
-//    scalar base + 32-bit register offset, zero VALU; boxes that stick out of the volume
-//    (edge tiles) take a guarded path that decodes coordinates on the fly;
-//  * the loads are issued one per item inside the multiply loop.
-// ----------------------------------------------------------------------------
-// 16-byte load through a buffer descriptor: address = descriptor base + voffset (VGPR, fixed per
-// lane) + soffset (SGPR).  No address VALU at all, which is the point here (T8 in the guide).
-__device__ __forceinline__ f32x4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset,
-                                               unsigned soffset) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voffset, (int)soffset, 0);
-  static_assert(sizeof(v) == 16, "raw_buffer_load_b128 must return 16 bytes");
-  return __builtin_bit_cast(f32x4, v);
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
 
 template <int NPF, int NE, int NQ, int IX, int IY>
 __device__ __forceinline__ void stage_offsets(unsigned (&off)[NPF], int tid, int Hi, int Wi,
@@ -374,6 +188,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
   auto commit = [&]() { stage_commit<NPF, NE>(tile, pf, tid); };
 
   f32x16 acc[TM][NT];
+  float am = 0.f;                               // max |y| of this thread's outputs (y_amax)
   // folded BN of this lane's channels: kept in registers for the narrow variants (32 per
   // N-tile), re-read per tile where the accumulators need the registers
   constexpr bool KEEP_AFFINE = (NT * TM <= 2) && (NT == 1);
@@ -495,11 +310,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
           const int cbase = (n0 + n) * 32 + 4 * h;
           if constexpr (KEEP_AFFINE) {
             store_tile<0>(acc[m][n], af[n], p.relu, p.y + vox * COUT + cbase,
-                          p.res ? p.res + rvox * COUT + cbase : nullptr);
+                          p.res ? p.res + rvox * COUT + cbase : nullptr, am);
           } else {
             const Affine a1 = load_affine(p.scale, p.shift, cbase);
             store_tile<0>(acc[m][n], a1, p.relu, p.y + vox * COUT + cbase,
-                          p.res ? p.res + rvox * COUT + cbase : nullptr);
+                          p.res ? p.res + rvox * COUT + cbase : nullptr, am);
           }
         }
       }
@@ -508,9 +323,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
     ck = nck; t = nt_;
     if (t >= end) break;
   }
+  flush_amax(p.y_amax, am, reinterpret_cast<float*>(tile));
 }
 
-#include "conv_bf16x3.hpp"   // conv_bf16x3_kernel, deconv_bf16x3_kernel, pack_weights_bf16x3_kernel
+#include "conv_split.hpp"   // conv_split_kernel, deconv_split_kernel, pack_weights_split_kernel
 
 // ----------------------------------------------------------------------------
 // ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1), Cout = 32*NT.
@@ -590,6 +406,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
   auto commit = [&]() { stage_commit<NPF, NE>(tile, pf, tid); };
 
   f32x16 acc[4][NT];                                     // class = py*2 + px
+  float am = 0.f;
   constexpr bool KEEP_AFFINE = (NT == 1);
   Affine af[1];
   if constexpr (KEEP_AFFINE) af[0] = load_affine(p.scale, p.shift, 4 * h);
@@ -702,11 +519,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
             const int cbase = n * 32 + 4 * h;
             if constexpr (KEEP_AFFINE) {
               store_tile<COUT>(acc[c][n], af[0], p.relu, p.y + vox * COUT + cbase,
-                               p.res ? p.res + rvox * COUT + cbase : nullptr);
+                               p.res ? p.res + rvox * COUT + cbase : nullptr, am);
             } else {
               const Affine a1 = load_affine(p.scale, p.shift, cbase);
               store_tile<COUT>(acc[c][n], a1, p.relu, p.y + vox * COUT + cbase,
-                               p.res ? p.res + rvox * COUT + cbase : nullptr);
+                               p.res ? p.res + rvox * COUT + cbase : nullptr, am);
             }
           }
         }
@@ -715,6 +532,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void deconv3d_mfma_kernel(ConvParams p
     ck = nck; t = nt_;
     if (t >= end) break;
   }
+  flush_amax(p.y_amax, am, reinterpret_cast<float*>(tile));
 }
 
 // ----------------------------------------------------------------------------
@@ -1029,26 +847,6 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   out[idx] = (cin < cin_src) ? w[src] : 0.f;
 }
 
-template <typename K>
-int launch_tiles(K kernel, const ConvParams& p, size_t lds, hipStream_t s, int max_blocks, int ny = 1) {
-  if (lds > 64 * 1024) {
-    static thread_local const void* configured[48];
-    static thread_local int nconf = 0;
-    bool seen = false;
-    for (int i = 0; i < nconf; ++i) seen |= (configured[i] == (const void*)kernel);
-    if (!seen) {
-      if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds) != hipSuccess)
-        return DSM_ERR_LAUNCH;
-      if (nconf < 48) configured[nconf++] = (const void*)kernel;
-    }
-  }
-  if (p.force_blocks) max_blocks = p.force_blocks;     // dsm_conv3d_args.flags: persistent-grid A/B runs
-  int blocks = p.ntiles < max_blocks ? p.ntiles : max_blocks;
-  if (blocks >= 8) blocks &= ~7;                 // whole rounds over the 8 XCDs
-  hipLaunchKernelGGL(kernel, dim3(blocks, ny), dim3(NTHREADS), lds, s, p);
-  return dsm_launch_status();
-}
 
 // NSPLIT > 1: the layer has NT * NSPLIT N-tiles and each workgroup column (blockIdx.y) computes
 // NT of them -- for the tiny 128-channel layers at the bottom of GCNet's encoder (6 x 8 x 16
@@ -1066,43 +864,36 @@ int run_conv(ConvParams p, hipStream_t s, int nsplit = 1) {
   return launch_tiles(conv3d_mfma_kernel<S, NT, TM, CK, KZ, KXY, DIL>, p, lds, s, 512 / nsplit, nsplit);
 }
 
-template <int NT, int TM, int KZ, int DIL, int S = 1, bool S3IN = false, int NSPLIT = 1>
-int run_conv_bf16x3(ConvParams p, hipStream_t s) {
-  constexpr int TY = 4 * TM, IY = (TY - 1) * S + 2 * DIL + 1, IX = 31 * S + 2 * DIL + 1;
-  constexpr int NPF = (IY * IX * 4 + NTHREADS - 1) / NTHREADS;
-  p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, TY);
-  const long nt = (long)p.B * p.Do * p.nty * p.ntx;
-  if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
-  p.ntiles = (int)nt;
-  // two images; one workgroup per CU, or two where conv_bf16x3_two_per_cu says both fit
-  constexpr bool TWO = conv_bf16x3_two_per_cu<NT, TM, S, S3IN, DIL>();
-  const size_t lds = ((S == 1 && !S3IN) ? (size_t)2 * (TWO ? (IY * IX + 4) * 112 : NPF * 64 * 112)
-                                       : (size_t)2 * (IY * (S == 1 ? IX : 66) + 4) * 112) +
-                     2 * 32 * NT * NSPLIT * sizeof(float);           // + scale / shift of the whole layer
-  static_assert(!TWO || 2 * (2 * (IY * IX + 4) * 112 + 2 * 32 * NT * NSPLIT * 4) <= 160 * 1024, "two workgroups per CU");
-  static_assert(NSPLIT == 1 || TWO, "the N-split exists to put two workgroup columns on a CU");
-  return launch_tiles(conv_bf16x3_kernel<NT, TM, KZ, DIL, S, S3IN, NSPLIT>, p, lds, s,
-                      (TWO ? 512 : 256) / NSPLIT, NSPLIT);
-}
-
-template <int NT>
-int run_deconv_bf16x3(ConvParams p, hipStream_t s) {
-  p.ntx = dsm_cdiv(p.Wi, 32); p.nty = dsm_cdiv(p.Hi, 4);
-  const long nt = (long)p.B * p.Di * p.nty * p.ntx * 2;       // x2: z-parity
-  if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
-  p.ntiles = (int)nt;
-  const size_t lds = (size_t)2 * 6 * 32 * 208 + 2 * 32 * NT * sizeof(float);   // two images (79.9 KB) + scale / shift
-  // NT = 1 fits two workgroups per CU (198 registers, 2 x 80 KB of LDS): the second one computes while
-  // the first one's four-class epilogue (fp32 + S3 stores, skip read) drains
-  return launch_tiles(deconv_bf16x3_kernel<NT>, p, lds, s, NT == 1 ? 256 * DSM_DECONV_WGS : 256);
-}
-
 // Section 2 of a packed weight buffer (the pre-split bf16 planes), present for the shapes the
 // bf16x3 kernels cover: 3x3x3 with Cout 32/64, 3x3 with Cout 32/64/128; Cin % 16 == 0.
 size_t bf16x3_section_bytes(int Cin, int Cout, int kd, int k) {
   if (k != 3 || Cin % 16 != 0 || Cout % 32 != 0) return 0;
   if (kd == 3 ? Cout > 64 : Cout > 128) return 0;
   return (size_t)Cin * Cout * kd * 9 * 6;
+}
+// Section 3 (same shapes): a 16-byte header {absolute maximum of the weights, 0, 0, 0} followed by
+// the two fp16 planes of w * 2^ew (conv_split.hpp, PM = 2 | 1).
+size_t f16_section_bytes(int Cin, int Cout, int kd, int k) {
+  return bf16x3_section_bytes(Cin, Cout, kd, k) ? 16 + (size_t)Cin * Cout * kd * 9 * 4 : 0;
+}
+
+// the split sections behind the fp32 fragments of a packed buffer (`frag` = its first byte)
+int pack_split_sections(const float* w, char* frag, int Cin_src, int Cin, int Cout, int kd, int k,
+                        int transposed, hipStream_t s) {
+  const int ntaps = kd * k * k;
+  const long n = (long)Cin * Cout * ntaps;
+  if (!bf16x3_section_bytes(Cin, Cout, kd, k)) return DSM_OK;
+  char* sec2 = frag + n * 4;
+  hipLaunchKernelGGL(pack_weights_split_kernel<3>, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s, w,
+                     (unsigned short*)sec2, (const float*)nullptr, Cin, Cout, transposed, ntaps, Cin_src);
+  char* sec3 = sec2 + bf16x3_section_bytes(Cin, Cout, kd, k);
+  if (hipMemsetAsync(sec3, 0, 16, s) != hipSuccess) return DSM_ERR_LAUNCH;
+  const long nsrc = (long)Cin_src * Cout * ntaps;
+  hipLaunchKernelGGL(absmax_kernel, dim3(dsm_cdiv(dsm_cdiv(nsrc, 4), 256) < 64 ? dsm_cdiv(dsm_cdiv(nsrc, 4), 256) : 64),
+                     dim3(256), 0, s, w, nsrc, (float*)sec3);
+  hipLaunchKernelGGL(pack_weights_split_kernel<2>, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s, w,
+                     (unsigned short*)(sec3 + 16), (const float*)sec3, Cin, Cout, transposed, ntaps, Cin_src);
+  return DSM_OK;
 }
 
 // dsm_conv3d_args.flags & DSM_CONV_FP32_MFMA keeps a convolution on the fp32-input MFMA (A/B and
@@ -1127,7 +918,8 @@ int run_deconv(ConvParams p, hipStream_t s) {
 extern "C" size_t dsm_conv3d_packed_weight_bytes(int Cin, int Cout, int transposed) {
   (void)transposed;
   if (Cin <= 0 || Cout <= 0) return 0;
-  return (size_t)Cin * Cout * 27 * sizeof(float) + bf16x3_section_bytes(Cin, Cout, 3, 3);
+  return (size_t)Cin * Cout * 27 * sizeof(float) + bf16x3_section_bytes(Cin, Cout, 3, 3) +
+         f16_section_bytes(Cin, Cout, 3, 3);
 }
 
 extern "C" int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed, int Cin, int Cout,
@@ -1140,15 +932,13 @@ extern "C" int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed, int 
   hipLaunchKernelGGL(pack_weights_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const float*)w_torch, (float*)w_packed, Cin, Cout,
                      transposed, 27, Cin);
-  if (bf16x3_section_bytes(Cin, Cout, 3, 3))
-    hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const float*)w_torch,
-                       (unsigned short*)((float*)w_packed + n), Cin, Cout, transposed, 27, Cin, 0);
-  return dsm_launch_status();
+  const int rc = pack_split_sections((const float*)w_torch, (char*)w_packed, Cin, Cin, Cout, 3, 3,
+                                     transposed, (hipStream_t)stream);
+  return rc != DSM_OK ? rc : dsm_launch_status();
 }
 
-static int conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, int Cin,
-                             int Cout, int kd, int k, int s3order, dsm_stream_t stream) {
+extern "C" int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, int Cin,
+                                     int Cout, int kd, int k, dsm_stream_t stream) {
   DSM_REQUIRE(w_torch && w_packed && w_torch != w_packed, DSM_ERR_ARG);
   DSM_REQUIRE(Cin_src > 0 && Cin >= Cin_src && Cout > 0, DSM_ERR_ARG);
   DSM_REQUIRE((kd == 1 || kd == 3) && (k == 1 || k == 3), DSM_ERR_UNSUPPORTED);
@@ -1159,39 +949,32 @@ static int conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, i
   hipLaunchKernelGGL(pack_weights_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const float*)w_torch, (float*)w_packed, Cin, Cout, 0,
                      ntaps, Cin_src);
-  if (bf16x3_section_bytes(Cin, Cout, kd, k))
-    hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const float*)w_torch,
-                       (unsigned short*)((float*)w_packed + n), Cin, Cout, 0, ntaps, Cin_src, s3order);
+  const int rc = pack_split_sections((const float*)w_torch, (char*)w_packed, Cin_src, Cin, Cout, kd, k,
+                                     0, (hipStream_t)stream);
+  return rc != DSM_OK ? rc : dsm_launch_status();
+}
+
+extern "C" int dsm_absmax(const void* x, size_t n, float* amax, dsm_stream_t stream) {
+  DSM_REQUIRE(x && amax && n > 0, DSM_ERR_ARG);
+  DSM_REQUIRE(dsm_aligned16(x), DSM_ERR_ALIGN);
+  dsm_clear_stale_error();
+  const long blocks = dsm_cdiv(dsm_cdiv((long)n, 4), 256);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048), dim3(256), 0,
+                     (hipStream_t)stream, (const float*)x, (long)n, amax);
   return dsm_launch_status();
-}
-
-extern "C" int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, int Cin,
-                                     int Cout, int kd, int k, dsm_stream_t stream) {
-  return conv_pack_weights(w_torch, w_packed, Cin_src, Cin, Cout, kd, k, 0, stream);
-}
-
-// The same buffer with the bf16x3 section in the k-slot order of an S3-input launch
-// (dsm_conv3d_args.x_s3): 3x3(x3) kernels, Cin % 32 == 0.
-extern "C" int dsm_conv_pack_weights_s3in(const void* w_torch, void* w_packed, int Cin, int Cout,
-                                          int kd, int k, dsm_stream_t stream) {
-  DSM_REQUIRE(Cin > 0 && Cin % 32 == 0 && k == 3, DSM_ERR_UNSUPPORTED);
-  DSM_REQUIRE(bf16x3_section_bytes(Cin, Cout, kd, k) != 0, DSM_ERR_UNSUPPORTED);
-  return conv_pack_weights(w_torch, w_packed, Cin, Cin, Cout, kd, k, 1, stream);
 }
 
 extern "C" size_t dsm_conv_packed_weight_bytes(int Cin, int Cout, int kd, int k) {
   if (Cin <= 0 || Cout <= 0) return 0;
   if (!((kd == 1 || kd == 3) && (k == 1 || k == 3))) return 0;
-  return (size_t)Cin * Cout * kd * k * k * sizeof(float) + bf16x3_section_bytes(Cin, Cout, kd, k);
+  return (size_t)Cin * Cout * kd * k * k * sizeof(float) + bf16x3_section_bytes(Cin, Cout, kd, k) +
+         f16_section_bytes(Cin, Cout, kd, k);
 }
 
 namespace {
-// One place decides the kernel variant; dsm_conv3d_fwd launches it, dsm_conv3d_plan names it.
-struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; int nsplit = 1; };   // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1, 4 conv cout1 z-sliding, 5 conv bf16x3, 6 deconv bf16x3
 
-int make_plan(const dsm_conv3d_args* a, Plan* pl) {
-  DSM_REQUIRE(a && (a->x || a->x_s3) && !(a->x && a->x_s3) && a->w_packed && (a->y || a->y_s3), DSM_ERR_ARG);
+int make_plan_f32(const dsm_conv3d_args* a, Plan* pl) {
+  DSM_REQUIRE(a && a->x && a->w_packed && (a->y || a->y_s3), DSM_ERR_ARG);
   DSM_REQUIRE(a->B > 0 && a->Cin > 0 && a->Cout > 0, DSM_ERR_ARG);
   DSM_REQUIRE(a->Di > 0 && a->Hi > 0 && a->Wi > 0 && a->Do > 0 && a->Ho > 0 && a->Wo > 0,
               DSM_ERR_ARG);
@@ -1199,9 +982,9 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   DSM_REQUIRE(!a->transposed || a->stride == 2, DSM_ERR_UNSUPPORTED);
   DSM_REQUIRE(a->relu >= 0 && a->relu <= 2, DSM_ERR_ARG);
   DSM_REQUIRE(a->Cin % 16 == 0, DSM_ERR_UNSUPPORTED);   // chunk sizes 8 and 16 both divide it
-  DSM_REQUIRE(dsm_aligned16(a->x) && dsm_aligned16(a->x_s3) && dsm_aligned16(a->w_packed) &&
+  DSM_REQUIRE(dsm_aligned16(a->x) && dsm_aligned16(a->w_packed) &&
               dsm_aligned16(a->y) && dsm_aligned16(a->y_s3), DSM_ERR_ALIGN);
-  if (a->x_s3) DSM_REQUIRE(a->Cin % 32 == 0, DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE(a->precision == DSM_PREC_F32 || a->precision == DSM_PREC_F16X2 || a->precision == DSM_PREC_F16, DSM_ERR_ARG);
   const int kd = a->kd ? a->kd : 3, k = a->k ? a->k : 3, dil = a->dil ? a->dil : 1;
   DSM_REQUIRE((kd == 1 || kd == 3) && (k == 1 || k == 3) && (dil == 1 || dil == 2),
               DSM_ERR_UNSUPPORTED);
@@ -1259,14 +1042,14 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
     *pl = Plan{5, 1, NT, TM, 16, kd, 3, dil};
     // N-split (2-D layers, fp32 input): at most one round of 8-row tiles -- every workgroup's prologue
     // and epilogue exposed -- becomes two workgroup columns of half the output blocks, two per CU
-    if (kd == 1 && !a->x_s3 && TM == 2 && dil == 1 && (NT == 2 || NT == 4) && tiles8 <= 256 &&
+    if (kd == 1 && TM == 2 && dil == 1 && (NT == 2 || NT == 4) && tiles8 <= 256 &&
         !(a->flags & DSM_CONV_NO_NSPLIT)) {
       pl->NT = NT / 2; pl->nsplit = 2;
     }
     // the 64-channel 3-D layers on 4-row tiles (the bottom of the hourglass: 216 tiles, one serial chain
     // of 1,296 MFMAs per wave): two columns of 32 channels halve the chain
     // (one round of tiles only: 43.0 vs 44.7 us with 216 tiles; with 432 the two columns queue: 72.5 vs 67.4)
-    if (kd == 3 && !a->x_s3 && TM == 1 && NT == 2 && !(a->flags & DSM_CONV_NO_NSPLIT) &&
+    if (kd == 3 && TM == 1 && NT == 2 && !(a->flags & DSM_CONV_NO_NSPLIT) &&
         (long)a->B * a->Do * dsm_cdiv(a->Ho, 4) * dsm_cdiv(a->Wo, 32) <= 256) {
       pl->NT = 1; pl->nsplit = 2;
     }
@@ -1295,6 +1078,19 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   if (NT >= 2 && tiles4 <= 64 && pl->TM == 1) { pl->nsplit = NT; pl->NT = 1; }
   return DSM_OK;
 }
+// precision: the split kernels (kinds 5, 6) also exist on fp16 terms (conv_split.hpp); every other
+// kernel computes in fp32 whatever `precision` says
+int make_plan(const dsm_conv3d_args* a, Plan* pl) {
+  const int rc = make_plan_f32(a, pl);
+  if (rc != DSM_OK) return rc;
+  pl->pm = 3;
+  if ((pl->kind == 5 || pl->kind == 6) && a->precision != DSM_PREC_F32) {
+    DSM_REQUIRE(a->x_amax != nullptr, DSM_ERR_ARG);      // the input's absolute maximum (device scalar)
+    DSM_REQUIRE(!a->y_s3, DSM_ERR_UNSUPPORTED);          // S3 is the bf16x3 hand-over format
+    pl->pm = a->precision == DSM_PREC_F16X2 ? 2 : 1;
+  }
+  return DSM_OK;
+}
 }  // namespace
 
 extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
@@ -1311,14 +1107,16 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
     case 1: snprintf(buf, len, "deconv3d_mfma_kernel<NT=%d,CK=%d>", pl.NT, pl.CK); break;
     case 2: snprintf(buf, len, "conv3d_cout1_kernel<CK=%d>", pl.CK); break;
     case 4: snprintf(buf, len, "conv3d_cout1_zslide_kernel"); break;
-    case 5:
-      if (pl.KZ == 3 && pl.S == 2) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<S=2,NT=%d,TM=%d%s>", pl.NT, pl.TM, a->x_s3 ? ",S3IN" : "");
-      else if (pl.KZ == 3 && pl.nsplit > 1) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>x%d", pl.NT, pl.TM, pl.nsplit);
-      else if (pl.KZ == 3) snprintf(buf, len, "conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d%s>", pl.NT, pl.TM, a->x_s3 ? ",S3IN" : "");
-      else if (pl.nsplit > 1) snprintf(buf, len, "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>x%d", pl.NT, pl.TM, pl.DIL, pl.nsplit);
-      else snprintf(buf, len, "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d%s>", pl.NT, pl.TM, pl.DIL, a->x_s3 ? ",S3IN" : "");
+    case 5: {
+      const char* pr = pl.pm == 3 ? "bf16x3" : (pl.pm == 2 ? "f16x2" : "f16");
+      if (pl.KZ == 3 && pl.S == 2) snprintf(buf, len, "conv3d_%s_mfma_kernel<S=2,NT=%d,TM=%d>", pr, pl.NT, pl.TM);
+      else if (pl.KZ == 3 && pl.nsplit > 1) snprintf(buf, len, "conv3d_%s_mfma_kernel<NT=%d,TM=%d>x%d", pr, pl.NT, pl.TM, pl.nsplit);
+      else if (pl.KZ == 3) snprintf(buf, len, "conv3d_%s_mfma_kernel<NT=%d,TM=%d>", pr, pl.NT, pl.TM);
+      else if (pl.nsplit > 1) snprintf(buf, len, "conv2d_%s_mfma_kernel<NT=%d,TM=%d,DIL=%d>x%d", pr, pl.NT, pl.TM, pl.DIL, pl.nsplit);
+      else snprintf(buf, len, "conv2d_%s_mfma_kernel<NT=%d,TM=%d,DIL=%d>", pr, pl.NT, pl.TM, pl.DIL);
       break;
-    case 6: snprintf(buf, len, "deconv3d_bf16x3_mfma_kernel<NT=%d>", pl.NT); break;
+    }
+    case 6: snprintf(buf, len, "deconv3d_%s_mfma_kernel<NT=%d>", pl.pm == 3 ? "bf16x3" : (pl.pm == 2 ? "f16x2" : "f16"), pl.NT); break;
     default: snprintf(buf, len, "deconv3d_cout1_kernel"); break;
   }
   return DSM_OK;
@@ -1331,9 +1129,9 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   // the S3 second output exists in the epilogue of the bf16x3 kernels only; an S3 input is
   // understood by the bf16x3 convolution (not the transposed one) only
   if (a->y_s3) DSM_REQUIRE(pl.kind == 5 || pl.kind == 6, DSM_ERR_UNSUPPORTED);
-  if (a->x_s3) DSM_REQUIRE(pl.kind == 5, DSM_ERR_UNSUPPORTED);
   ConvParams p;
-  p.x = a->x_s3 ? (const float*)a->x_s3 : (const float*)a->x; p.w = (const float*)a->w_packed; p.scale = a->scale;
+  p.x = (const float*)a->x; p.w = (const float*)a->w_packed; p.scale = a->scale;
+  p.x_amax = a->x_amax; p.w_amax = nullptr; p.y_amax = a->y_amax;
   p.shift = a->shift; p.res = (const float*)a->residual; p.y = (float*)a->y;
   p.ys3 = (unsigned char*)a->y_s3;
   p.force_blocks = (a->flags >> DSM_CONV_BLOCKS_SHIFT) & 0xffff;
@@ -1342,8 +1140,7 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   p.Dr = a->Dr; p.Hr = a->Hr; p.Wr = a->Wr; p.relu = a->relu;
   p.ntx = p.nty = p.ntiles = 0;
   {
-    const unsigned long xb = (a->x_s3 ? 6ul : 4ul) * a->B * a->Di * a->Hi * a->Wi * a->Cin;
-    if (a->x_s3) DSM_REQUIRE(xb < (1ul << 31), DSM_ERR_UNSUPPORTED);          // the out-of-range marker must lie past the tensor
+    const unsigned long xb = 4ul * a->B * a->Di * a->Hi * a->Wi * a->Cin;
     const int kd_ = a->kd ? a->kd : 3, k_ = a->k ? a->k : 3;
     const unsigned long wb = 4ul * a->Cin * a->Cout * kd_ * k_ * k_;
     DSM_REQUIRE(xb < (1ul << 32) && wb < (1ul << 32), DSM_ERR_UNSUPPORTED);   // 32-bit buffer offsets
@@ -1359,30 +1156,19 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
     hipLaunchKernelGGL(deconv3d_cout1_kernel, dim3((unsigned)nt), dim3(NTHREADS), lds, s, p);
     return dsm_launch_status();
   }
-  if (pl.kind == 6) {
-    p.w = (const float*)a->w_packed + (size_t)a->Cin * a->Cout * 27;          // section 2
-    p.wbytes = (unsigned)bf16x3_section_bytes(a->Cin, a->Cout, 3, 3);
-    return pl.NT == 1 ? run_deconv_bf16x3<1>(p, s) : run_deconv_bf16x3<2>(p, s);
-  }
-  if (pl.kind == 5) {
-    p.w = (const float*)a->w_packed + (size_t)a->Cin * a->Cout * pl.KZ * 9;   // section 2
-    p.wbytes = (unsigned)bf16x3_section_bytes(a->Cin, a->Cout, pl.KZ, 3);
-    if (pl.S == 2) return a->x_s3 ? run_conv_bf16x3<2, 1, 3, 1, 2, true>(p, s) : run_conv_bf16x3<2, 1, 3, 1, 2>(p, s);
-    if (pl.nsplit == 2) {                         // 2-D layers of 64 / 128 channels in two workgroup columns
-      if (pl.KZ == 1 && pl.NT == 1 && pl.TM == 2 && pl.DIL == 1) return run_conv_bf16x3<1, 2, 1, 1, 1, false, 2>(p, s);
-      if (pl.KZ == 1 && pl.NT == 2 && pl.TM == 2 && pl.DIL == 1) return run_conv_bf16x3<2, 2, 1, 1, 1, false, 2>(p, s);
-      if (pl.KZ == 3 && pl.NT == 1 && pl.TM == 1) return run_conv_bf16x3<1, 1, 3, 1, 1, false, 2>(p, s);
-      return DSM_ERR_UNSUPPORTED;
+  if (pl.kind == 5 || pl.kind == 6) {
+    const int kz = pl.kind == 6 ? 3 : pl.KZ;
+    const char* sec2 = (const char*)a->w_packed + (size_t)a->Cin * a->Cout * kz * 9 * 4;
+    if (pl.pm == 3) {
+      p.w = (const float*)sec2;
+      p.wbytes = (unsigned)bf16x3_section_bytes(a->Cin, a->Cout, kz, 3);
+      return dispatch_split<3>(pl, p, s);
     }
-#define DSM_CASE_BF(NT_, TM_, KZ_, DIL_) \
-    if (pl.NT == NT_ && pl.TM == TM_ && pl.KZ == KZ_ && pl.DIL == DIL_) \
-      return a->x_s3 ? run_conv_bf16x3<NT_, TM_, KZ_, DIL_, 1, true>(p, s) : run_conv_bf16x3<NT_, TM_, KZ_, DIL_>(p, s)
-    DSM_CASE_BF(1, 4, 3, 1); DSM_CASE_BF(1, 2, 3, 1); DSM_CASE_BF(2, 2, 3, 1); DSM_CASE_BF(2, 1, 3, 1);
-    DSM_CASE_BF(1, 4, 1, 1); DSM_CASE_BF(1, 2, 1, 1); DSM_CASE_BF(2, 2, 1, 1); DSM_CASE_BF(2, 1, 1, 1);
-    DSM_CASE_BF(4, 2, 1, 1);
-    DSM_CASE_BF(4, 2, 1, 2);
-#undef DSM_CASE_BF
-    return DSM_ERR_UNSUPPORTED;
+    const char* sec3 = sec2 + bf16x3_section_bytes(a->Cin, a->Cout, kz, 3);
+    p.w_amax = (const float*)sec3;
+    p.w = (const float*)(sec3 + 16);
+    p.wbytes = (unsigned)(f16_section_bytes(a->Cin, a->Cout, kz, 3) - 16);
+    return dsmk::run_split_f16(pl, p, s);
   }
   if (pl.kind == 4) {
     p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, 8);

@@ -696,7 +696,7 @@ extern "C" int dsm_conv3d_s3_fwd(const dsm_conv3d_s3_args* a, dsm_stream_t strea
               DSM_ERR_ARG);
   DSM_REQUIRE(a->Cin > 0 && a->Cin % 32 == 0 && a->Cout == 32, DSM_ERR_UNSUPPORTED);
   DSM_REQUIRE(a->Do <= a->Di && a->Ho <= a->Hi && a->Wo <= a->Wi, DSM_ERR_ARG);
-  DSM_REQUIRE(a->relu >= 0 && a->relu <= 2 && a->tiling >= 0 && a->tiling <= 2, DSM_ERR_ARG);
+  DSM_REQUIRE(a->relu >= 0 && a->relu <= 2, DSM_ERR_ARG);
   if (a->vol_virtual) DSM_REQUIRE(a->Cin % 64 == 0, DSM_ERR_UNSUPPORTED);   // [left | right], 32-channel groups each
   if (a->residual)
     DSM_REQUIRE(a->Dr >= a->Do && a->Hr >= a->Ho && a->Wr >= a->Wo, DSM_ERR_ARG);
@@ -715,7 +715,5 @@ extern "C" int dsm_conv3d_s3_fwd(const dsm_conv3d_s3_args* a, dsm_stream_t strea
   p.vol = a->vol_virtual ? 1 : 0; p.vol_mask_left = a->vol_mask_left ? 1 : 0;
   p.wbytes = (unsigned)dsm_conv3d_s3_packed_weight_bytes(a->Cin, 32);
   dsm_clear_stale_error();
-  const int tiling = a->tiling ? a->tiling : S3_DEFAULT_TILING;
-  if (tiling == 1) return launch_conv_s3<0>(p, a, (hipStream_t)stream);
-  return launch_conv_s3<1>(p, a, (hipStream_t)stream);
+  return launch_conv_s3<0>(p, a, (hipStream_t)stream);
 }

@@ -1,43 +1,37 @@
-// bf16x3 kernels: fp32 convolution and transposed convolution on the bf16 matrix pipe.
-// Included by conv3d.hip inside its anonymous namespace, after the shared helpers (ConvParams,
-// first_tile, store_tile, buffer_load16, make_rsrc, static_for, DSM_STAMP) -- one translation
-// unit, so that the diagnostic stamp buffer and the launch helpers are shared.
+// Split-operand kernels: fp32 convolution and transposed convolution on the 16-bit matrix pipe.
+// Included by conv3d.hip (PM = 3) and conv_f16.hip (PM = 2, 1) after conv_common.hpp.
+//
+// PM (precision mode) = number of 16-bit terms an fp32 operand is split into:
+//   PM = 3  "bf16x3": v = hi + mid + lo in bf16 (exact split), six MFMAs per product -- fp32 accuracy,
+//           no scaling needed (bf16 has the fp32 exponent range);
+//   PM = 2  "f16x2":  v * 2^e = hi + lo in fp16 (22 significand bits), three MFMAs per product
+//           (wl xh + wh xl + wh xh) -- fp32 accuracy at half the MFMAs.  fp16 has a 5-bit exponent,
+//           so every tensor is scaled by a power of two chosen from its absolute maximum (activations:
+//           a device scalar written by the producing kernel's epilogue, dsm_conv3d_args.x_amax /
+//           y_amax; weights: at pack time) so that the maximum lands in [2^12, 2^13); the combined
+//           2^-(ex + ew) is folded into the epilogue's scale.  Residuals that fall below fp16's normal
+//           range become subnormals (absolute error 2^-25 against a maximum of 2^12), which the MFMA
+//           keeps (f16 denormals are not flushed on gfx950: tests/test_f16_gpu.py);
+//   PM = 1  "f16":    operands rounded to fp16 (hi only), one MFMA per product, fp32 accumulate --
+//           the reduced-precision mode of BASELINE config #5.
 #pragma once
 
-// ----------------------------------------------------------------------------
-// fp32 convolution on the bf16 matrix pipe ("bf16x3"): Conv3d k3 s1 p1, Cout = 32, Cin % 16 == 0.
-//
-// The fp32-input MFMA runs at the vector rate (157 TF/s, 1/16 of bf16) and is the wall of this
-// path.  Here every fp32 operand is split EXACTLY into three bf16 terms,
-//     v = hi + mid + lo,   hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid)
-// (round-to-nearest; the two subtractions are exact in fp32, so the three terms carry all 24
-// bits of v up to a final rounding of 2^-25 |v|), and a product is evaluated as the six largest
-// of the nine cross terms
-//     w*x ~= wh*xh + wh*xm + wm*xh + wh*xl + wl*xh + wm*xm
-// on v_mfma_f32_32x32x16_bf16: every bf16 x bf16 product is exact in the fp32 accumulator, the
-// three dropped terms are <= 3 * 2^-25 |w*x| (below the rounding of an fp32 fma chain of this
-// length), and accumulation is fp32.  Six MFMAs at 16x the fp32 rate = 2.67x the throughput at
-// fp32 accuracy -- parity tests run at the same tolerances as the fp32 kernel.
-//
-// Structure: workgroup = 4 waves = output tile 1 z x 16 y x 32 x; wave w owns rows 4w..4w+3 (four
-// 32x32 accumulators).  A chunk = one z-tap plane x 16 input channels: its (18 x 34)-voxel halo is
-// staged global -> VGPR (fp32, buffer loads with zero address VALU as above) -> split -> LDS as
-// [voxel][plane 3][16 bf16] at a pitch of 7 x 16 B (conflict-free ds_read_b128 for the 16-lane
-// read groups).  Per tap: 3 weight fragments (buffer loads, 2 items ahead, the ring running on
-// across chunks) and per row 3 activation fragments (LDS) feed 6 MFMAs.
-// One workgroup per CU, one wave per SIMD, TWO LDS images: the next chunk is loaded, split and
-// written into the other image from inside this chunk's MFMA stream -- half an element (11 VALU
-// + 3 ds_write_b64) per 6-MFMA group, in the wave's own issue gaps (a 32x32x16 MFMA holds vector
-// issue for 8 of its 32 cycles).  Measured on the first version (one image, two workgroups per
-// CU, split at the commit between two barriers): VALU beside a PARTNER wave's MFMA stream
-// issues about once per MFMA -- the commit took 18-21 % of every wave's time -- which is the same
-// effect that shaped the fp32 kernel above.  One barrier per chunk is left.
-// Weights: pre-split, section 2 of the packed buffer, [Cin/16][dz][tap9][plane][lane][8 bf16].
-// ----------------------------------------------------------------------------
+#ifndef DSM_STAMP
+#define DSM_STAMP(slot) do {} while (0)
+#define DSM_STAMP_INIT() do {} while (0)
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int PM> struct Prec;
+template <> struct Prec<3> { static constexpr int NP = 3, NPW = 3; typedef bf16x8 frag; };
+template <> struct Prec<2> { static constexpr int NP = 2, NPW = 2; typedef f16x8 frag; };
+template <> struct Prec<1> { static constexpr int NP = 1, NPW = 2; typedef f16x8 frag; };   // reads plane 0 of the f16x2 packing
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {        // low half = a
   const f32x2 t = {a, b};
@@ -46,24 +40,75 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {        // low 
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
-// four fp32 -> three planes of four bf16 (8 bytes each)
-__device__ __forceinline__ void split3(const f32x4 v, u32x2 (&pl)[3]) {
-  float r0 = v.x, r1 = v.y, r2 = v.z, r3 = v.w;
+// two fp32 values -> their NP planes (one dword per plane, low half = a).  PM < 3: `sx` = 2^ex.
+template <int PM>
+__device__ __forceinline__ void split_pair(float a, float b, float sx, unsigned (&pl)[Prec<PM>::NP]) {
+  if constexpr (PM == 3) {
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const unsigned a = pack_bf16(r0, r1), b = pack_bf16(r2, r3);
-    pl[k].x = a; pl[k].y = b;
-    if (k < 2) { r0 -= bf16_lo(a); r1 -= bf16_hi(a); r2 -= bf16_lo(b); r3 -= bf16_hi(b); }
+    for (int q = 0; q < 3; ++q) {
+      pl[q] = pack_bf16(a, b);
+      if (q < 2) { a -= bf16_lo(pl[q]); b -= bf16_hi(pl[q]); }
+    }
+  } else {
+    // hi = f16(v * sx) straight from the fp32 value (v_fma_mix{lo,hi}_f16: an fp32 fma -- exact, sx is a
+    // power of two -- rounded once to fp16), the residual with hi read as an fp16 operand
+    // (v_fma_mix_f32): five plain VALU instructions per pair and no packed-fp32 ones, which issue
+    // slowly beside an MFMA stream (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+    unsigned hi;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(a), "s"(sx));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(b), "s"(sx));
+    pl[0] = hi;
+    if constexpr (PM == 2) {
+      float r0, r1;
+      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a), "s"(sx), "v"(hi));
+      asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(b), "s"(sx), "v"(hi));
+      const f32x2 r = {r0, r1};
+      pl[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+    }
+  }
+}
+
+// one 32x32x16 product group: c += w * x on PM terms (small terms first)
+template <int PM>
+__device__ __forceinline__ void mma32(f32x16& c, const typename Prec<PM>::frag (&w)[Prec<PM>::NP],
+                                      const typename Prec<PM>::frag (&x)[Prec<PM>::NP]) {
+  if constexpr (PM == 3) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], x[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[0], c, 0, 0, 0);
+  } else if constexpr (PM == 2) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1], x[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], x[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], x[0], c, 0, 0, 0);
+  } else {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0], x[0], c, 0, 0, 0);
+  }
+}
+
+// scaling of a launch (PM < 3): sx = 2^ex multiplies the staged activations, `out` = 2^-(ex + ew)
+// is folded into the epilogue's scale
+struct SplitScale { float sx, out; };
+template <int PM>
+__device__ __forceinline__ SplitScale split_scale(const ConvParams& p) {
+  if constexpr (PM == 3) return SplitScale{1.f, 1.f};
+  else {
+    const int ex = dsm_amax_exponent(*p.x_amax), ew = dsm_amax_exponent(*p.w_amax);
+    return SplitScale{__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dsm_pow2f(ex)))),
+                      dsm_pow2f(-(ex + ew))};
   }
 }
 
 // Folded-BN scale / shift of a launch, staged once into LDS behind the two images: the epilogue
 // reads them with LDS latency instead of an L2 round trip per tile (stamps: the epilogue was 15 %
 // of a 64-channel 2-D layer's in-loop time, most of it waiting for these 2 x COUT floats).
+// `so`: the launch's output factor 2^-(ex + ew) (1 for PM = 3), folded into the scale here.
 __device__ __forceinline__ void stage_affine_lds(float* aff, const float* scale, const float* shift,
-                                                 int cout, int tid) {
+                                                 int cout, int tid, float so) {
   for (int i = tid; i < 2 * cout; i += NTHREADS)
-    aff[i] = i < cout ? (scale ? scale[i] : 1.f) : (shift ? shift[i - cout] : 0.f);
+    aff[i] = i < cout ? (scale ? scale[i] * so : so) : (shift ? shift[i - cout] : 0.f);
 }
 __device__ __forceinline__ Affine load_affine_lds(const float* aff, int cout, int cbase) {
   Affine a;
@@ -75,60 +120,88 @@ __device__ __forceinline__ Affine load_affine_lds(const float* aff, int cout, in
   return a;
 }
 
-// NT = Cout / 32; TM = 32x32 accumulator rows per wave (tile height 4 TM); KZ = 3: 3x3x3 on
-// volumes, KZ = 1: 3x3 on (B,1,H,W,C) views of NHWC maps; DIL: dilation in (y, x).
-// S = 2 (stride 2, DIL = 1, KZ = 3): the halo box is (2 TY + 1) x 65 voxels; its LDS image keeps
-// even and odd columns of a row apart (row pitch 66 voxels: 33 even, 33 odd) so that the lanes of
-// a fragment read, which step two input columns, stay 112 B apart.
-// S3IN: the input arrives in the S3 format of conv_s3.hip (fp32 pre-split into three bf16 planes by
-// the layer that produced it): staging is a 16-byte copy, six per voxel and chunk (3 planes x 2
-// units), and the operand split -- 16 % of this kernel's time by ablation, plus the bank conflicts
-// of its ds_write_b64 -- is gone from the MFMA stream.  A chunk of 16 k-slots is then units
-// 2 (ck & 1), 2 (ck & 1) + 1 of channel group ck / 2: k-slot j of lane half h is channel
-// 32 (ck / 2) + 16 (j / 4) + 4 (2 (ck & 1) + h) + (j & 3); the weights are packed in that order
-// (dsm_conv_pack_weights_s3in).
-// Variants whose registers (<= 236 at a forced occupancy of 2, no scratch) and LDS (two exact-size
-// images) let TWO workgroups share a CU: the second one computes while the first one's prologue /
-// epilogue runs -- what the transposed kernel gained 7-12 % from.  (The 16-row and 128-channel
-// variants need one CU's LDS or registers for themselves.)
-template <int NT, int TM, int S, bool S3IN, int DIL = 1>
-constexpr bool conv_bf16x3_two_per_cu() { return S == 1 && !S3IN && NT <= 2 && TM <= 2 && DIL == 1; }
-
+// ----------------------------------------------------------------------------
+// fp32 convolution on the 16-bit matrix pipe: Conv3d k3 p1 (KZ = 3) / Conv2d 3x3 (KZ = 1, on
+// (B,1,H,W,C) views of NHWC maps), Cout = 32 NT NSPLIT, Cin % 16 == 0.
+//
+// PM = 3 (bf16x3): every fp32 operand is split EXACTLY into three bf16 terms,
+//     v = hi + mid + lo,   hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid)
+// (round-to-nearest; the two subtractions are exact in fp32, so the three terms carry all 24
+// bits of v up to a final rounding of 2^-25 |v|), and a product is evaluated as the six largest
+// of the nine cross terms  w*x ~= wh*xh + wh*xm + wm*xh + wh*xl + wl*xh + wm*xm
+// on v_mfma_f32_32x32x16_bf16: every bf16 x bf16 product is exact in the fp32 accumulator, the
+// three dropped terms are <= 3 * 2^-25 |w*x| (below the rounding of an fp32 fma chain of this
+// length), and accumulation is fp32.  PM = 2 / 1: the fp16 forms described at the top of the file.
+//
+// Structure: workgroup = 4 waves = output tile 1 z x 4 TM y x 32 x; wave w owns rows TM w .. TM w +
+// TM - 1 (TM 32x32 accumulators per output block).  A chunk = one z-tap plane x 16 input channels:
+// its halo is staged global -> VGPR (fp32, buffer loads with zero address VALU) -> split -> LDS as
+// [voxel][plane NP][16 x 16-bit] at a pitch of (2 NP + 1) x 16 B (an odd number of 16-byte units:
+// conflict-free ds_read_b128 for the 16-lane read groups).  Per tap: NP weight fragments (buffer
+// loads, 2 items ahead, the ring running on across chunks) and per row NP activation fragments (LDS)
+// feed one product group.
+// One workgroup per CU (two where conv_split_two_per_cu says both fit), one wave per SIMD, TWO LDS
+// images: the next chunk is loaded, split and written into the other image from inside this
+// chunk's MFMA stream -- half an element per product group, in the wave's own issue gaps (a
+// 32x32x16 MFMA holds vector issue for 8 of its 32 cycles).  Measured on the first version (one
+// image, two workgroups per CU, split at the commit between two barriers): VALU beside a PARTNER
+// wave's MFMA stream issues about once per MFMA -- the commit took 18-21 % of every wave's time.
+// One barrier per chunk is left.
+// Weights: pre-split, [Cin/16][dz][tap9][n][plane NPW][lane][8 x 16-bit].
+//
+// NT = output blocks per workgroup; TM = accumulator rows per wave (tile height 4 TM); DIL:
+// dilation in (y, x).  S = 2 (stride 2, DIL = 1, KZ = 3): the halo box is (2 TY + 1) x 65 voxels;
+// its LDS image keeps even and odd columns of a row apart (row pitch 66 voxels: 33 even, 33 odd)
+// so that the lanes of a fragment read, which step two input columns, stay one pitch apart.
 // NSPLIT > 1 (N-split): the layer has NT * NSPLIT 32-channel output blocks and workgroup column
 // blockIdx.y computes NT of them -- a 128-channel 2-D layer with 240 tiles becomes 480 workgroups of
 // the 64-channel variant, two per CU, instead of 240 that leave every CU's prologue and epilogue
 // exposed (each workgroup stages the whole input tile; the weights are read once either way).
-template <int NT, int TM, int KZ, int DIL, int S = 1, bool S3IN = false, int NSPLIT = 1>
-__global__ __launch_bounds__(NTHREADS, (conv_bf16x3_two_per_cu<NT, TM, S, S3IN, DIL>() ? 2 : 1))
-void conv_bf16x3_kernel(ConvParams p) {
+// ----------------------------------------------------------------------------
+template <int NT, int TM, int S, int DIL = 1>
+constexpr bool conv_split_two_per_cu() { return S == 1 && NT <= 2 && TM <= 2 && DIL == 1; }
+
+template <int PM, int NT, int TM, int KZ, int DIL, int S = 1, int NSPLIT = 1>
+struct ConvSplitCfg {
+  static constexpr int NP = Prec<PM>::NP, NPW = Prec<PM>::NPW;
+  static constexpr int TY = 4 * TM, CK = 16;
+  static constexpr int IY = (TY - 1) * S + 2 * DIL + 1, IX = 31 * S + 2 * DIL + 1;
+  static constexpr int NVOX = IY * IX;
+  static constexpr int NE = NVOX * 4;                // staged 16-B fp32 quads per chunk
+  static constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
+  static constexpr int PITCH = 32 * NP + 16;         // bytes per voxel in LDS: NP planes x 32 B + 16 pad
+  static constexpr int RP = (S == 1) ? IX : 66;      // voxels per image row
+  static constexpr bool TWO = conv_split_two_per_cu<NT, TM, S, DIL>();
+  // S = 1: the last pass's tail quads land in padding behind the image -- or, where two workgroups
+  // share the CU, are not stored (exact-size image)
+  static constexpr int IMG = (S == 1) ? (TWO ? (NVOX + 4) * PITCH : NPF * 64 * PITCH) : (IY * RP + 4) * PITCH;
+  static constexpr int NTP = NT * NSPLIT;            // 32-channel output blocks of the layer
+  static constexpr int COUT = 32 * NTP;
+  static constexpr int LDS = 2 * IMG + 2 * COUT * 4; // two images + scale / shift of the whole layer
+  static_assert(!TWO || 2 * LDS <= 160 * 1024, "two workgroups per CU");
+  static_assert(NSPLIT == 1 || TWO, "the N-split exists to put two workgroup columns on a CU");
+};
+
+template <int PM, int NT, int TM, int KZ, int DIL, int S = 1, int NSPLIT = 1>
+__global__ __launch_bounds__(NTHREADS, (conv_split_two_per_cu<NT, TM, S, DIL>() ? 2 : 1))
+void conv_split_kernel(ConvParams p) {
   static_assert(S == 1 || (S == 2 && DIL == 1 && KZ == 3), "stride 2: 3x3x3, no dilation");
-  constexpr int TY = 4 * TM, NQ = S3IN ? 6 : 4, CK = 16;
-  constexpr int IY = (TY - 1) * S + 2 * DIL + 1, IX = 31 * S + 2 * DIL + 1;
-  constexpr int NVOX = IY * IX;
-  constexpr int NE = NVOX * NQ;                 // staged 16-B elements per chunk (fp32 quads, or S3 units)
-  constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;
-  constexpr int PITCH = 112;                    // bytes per voxel in LDS: 3 planes x 32 B + 16 pad
-  constexpr int RP = (S == 1) ? IX : 66;        // voxels per image row
-  constexpr bool TWO = conv_bf16x3_two_per_cu<NT, TM, S, S3IN, DIL>();
-  // fp32 input, S = 1: the last pass's tail quads land in padding behind the image -- or, where two
-  // workgroups share the CU, are not stored (exact-size image)
-  constexpr int IMG = (S == 1 && !S3IN) ? (TWO ? (NVOX + 4) * PITCH : NPF * 64 * PITCH) : (IY * RP + 4) * PITCH;
+  using C = ConvSplitCfg<PM, NT, TM, KZ, DIL, S, NSPLIT>;
+  using frag = typename Prec<PM>::frag;
+  constexpr int NP = C::NP, NPW = C::NPW, TY = C::TY, CK = C::CK, IX = C::IX, NE = C::NE,
+                NPF = C::NPF, PITCH = C::PITCH, RP = C::RP, IMG = C::IMG, NTP = C::NTP, COUT = C::COUT;
+  constexpr bool TWO = C::TWO;
   constexpr int NITEM = 9;
-  constexpr int NGROUP = NITEM * TM;            // (tap, row) groups of 6 NT MFMAs per chunk
+  constexpr int NGROUP = NITEM * TM;            // (tap, row) product groups per chunk
   constexpr int AHEAD = 3;                      // weight ring: two items ahead (eight measured the same, twice)
-  // staging schedule.  fp32 input, S = 1: one load per group over the first NPF groups, half an
-  // element split per group over the last 2 NPF.  S = 2 (ten elements for nine groups): every load
-  // in group 0, four halves per group from group 4.  S3 input: LPG loads per group from group 0,
-  // the same number of 16-byte stores per group over the last groups.
-  constexpr bool SHORT = !S3IN && (S == 2 || NGROUP - 2 * NPF < 2);   // few groups per chunk (4-row tiles, stride 2)
-  constexpr int LPG = S3IN ? (NPF + NGROUP / 2 - 1) / (NGROUP / 2) : (SHORT ? NPF : 1);   // loads per group
-  constexpr int CONV0 = S3IN ? NGROUP - (NPF + LPG - 1) / LPG
-                             : (SHORT ? 4 : NGROUP - 2 * NPF);   // first group that converts / stores
-  constexpr int CPG = S3IN ? LPG : (2 * NPF + (NGROUP - CONV0) - 1) / (NGROUP - CONV0);   // halves (stores) per group
+  // staging schedule.  S = 1: one load per group over the first NPF groups, half an element split
+  // per group over the last 2 NPF.  S = 2 (ten elements for nine groups) and the 4-row tiles: every
+  // load in group 0, CPG halves per group from group 4.
+  constexpr bool SHORT = S == 2 || NGROUP - 2 * NPF < 2;
+  constexpr int LPG = SHORT ? NPF : 1;          // loads per group
+  constexpr int CONV0 = SHORT ? 4 : NGROUP - 2 * NPF;      // first group that converts / stores
+  constexpr int CPG = (2 * NPF + (NGROUP - CONV0) - 1) / (NGROUP - CONV0);   // halves per group
   static_assert(NPF <= NGROUP * LPG && CONV0 >= 2, "staging schedule");
-  static_assert(!S3IN || CONV0 > (NPF + LPG - 1) / LPG, "a store must come after its load");
-  constexpr int NTP = NT * NSPLIT;              // 32-channel output blocks of the layer
-  constexpr int COUT = 32 * NTP;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -139,27 +212,23 @@ void conv_bf16x3_kernel(ConvParams p) {
   int step, end;
   int t = first_tile(p.ntiles, step, end);
   if (t >= end) return;
+  const SplitScale ss = split_scale<PM>(p);
 
   // Staging is branch-free: element k of this thread sits at voxel (yy, xx) of the halo box;
   // its byte offset from the box origin is fixed per launch, and a voxel outside the volume is
   // read through the buffer descriptor at an out-of-range offset (hardware returns zeros).
   f32x4 pf[NPF];
   unsigned goff[NPF], yx[NPF];
-  const unsigned s3row = S3IN ? (unsigned)(p.Cin >> 5) * 12u * (unsigned)p.Wi : 0u;   // 16-B units per input row y (S3)
 #pragma unroll
   for (int k = 0; k < NPF; ++k) {
     const int e = tid + k * NTHREADS;
-    const int v = e / NQ, q = e % NQ;
+    const int v = e / 4, q = e % 4;
     const int yy = v / IX, xx = v % IX;
-    if constexpr (S3IN)         // unit (plane q / 2, g = q & 1 of the chunk's unit pair) of voxel (yy, xx)
-      goff[k] = 16u * ((unsigned)yy * s3row + (unsigned)(4 * (q >> 1) + (q & 1)) * (unsigned)p.Wi + (unsigned)xx);
-    else
-      goff[k] = 4u * (unsigned)((yy * p.Wi + xx) * p.Cin + 4 * q);
+    goff[k] = 4u * (unsigned)((yy * p.Wi + xx) * p.Cin + 4 * q);
     yx[k] = e < NE ? ((unsigned)yy << 16 | (unsigned)xx) : 0x7fff0000u;   // tail: never in range
   }
   const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.wbytes);
-  const unsigned plane_bytes = S3IN ? 16u * s3row * (unsigned)p.Hi
-                                    : 4u * (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)p.Cin;
+  const unsigned plane_bytes = 4u * (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)p.Cin;
 
   // (tile, dz, ck) of the chunk being multiplied and of the one being staged
   struct Pos { int t, dz, ck, yb, xb, z; unsigned base; };   // base: byte offset of the box origin in the tile's own z-plane (mod 2^32)
@@ -168,10 +237,7 @@ void conv_bf16x3_kernel(ConvParams p) {
     q.xb = (id % p.ntx) * 32 * S - DIL; id /= p.ntx;
     q.yb = (id % p.nty) * TY * S - DIL; id /= p.nty;
     q.z = (id % p.Do) * S; const int b = id / p.Do;          // input plane of the centre z-tap
-    if constexpr (S3IN)
-      q.base = (unsigned)(16l * ((((long)b * p.Di + q.z) * p.Hi + q.yb) * (long)s3row + q.xb));
-    else
-      q.base = (unsigned)(4l * (((((long)b * p.Di + q.z) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
+    q.base = (unsigned)(4l * (((((long)b * p.Di + q.z) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
     return q;
   };
   auto advance = [&](Pos q) {                   // next chunk: ck fastest, then dz, then the tile
@@ -194,8 +260,7 @@ void conv_bf16x3_kernel(ConvParams p) {
     }
   };
   auto chunk_rsrc = [&](const Pos& q, bool live) {
-    const long off = (long)(q.dz - KZ / 2) * (long)plane_bytes +
-                     (S3IN ? (long)((q.ck >> 1) * 12 + 2 * (q.ck & 1)) * p.Wi * 16 : (long)q.ck * (CK * 4));
+    const long off = (long)(q.dz - KZ / 2) * (long)plane_bytes + (long)q.ck * (CK * 4);
     return make_rsrc(reinterpret_cast<const char*>(p.x) + off, live ? p.xbytes : 0u);
   };
   auto live_of = [&](const Pos& q) {            // wave-uniform: a tile exists and its z-tap plane is inside
@@ -204,30 +269,21 @@ void conv_bf16x3_kernel(ConvParams p) {
   };
   // weights: [ck][dz][tap9][n][plane][lane][16 B]
   auto wbase_of = [&](const Pos& q) {
-    return (unsigned)((q.ck * KZ + q.dz) * 9) * (NTP * 3 * 64 * 16) + (unsigned)n0 * (3 * 64 * 16);
+    return (unsigned)((q.ck * KZ + q.dz) * 9) * (NTP * NPW * 64 * 16) + (unsigned)n0 * (NPW * 64 * 16);
   };
 
   // LDS write address of this thread's quad k.  S = 1: voxel (tid >> 2) + 64 k, an immediate
   // per k; S = 2: the even/odd row layout, one register per k.
   const int wr_off = (tid >> 2) * PITCH + (tid & 3) * 8;
-  int wofs[(S == 1 && !S3IN) ? 1 : NPF];
-  if constexpr (S3IN) {
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-      const int e = tid + k * NTHREADS;
-      const int v = min(e, NE - 1) / NQ, q = e % NQ, yy = v / IX, xx = v % IX;
-      const int vox = (S == 1) ? v : yy * RP + (xx & 1) * 33 + (xx >> 1);
-      wofs[k] = e < NE ? vox * PITCH + (q >> 1) * 32 + (q & 1) * 16
-                       : (IY * RP) * PITCH + (tid % 28) * 16;    // the tail: spare voxels behind the image
-    }
-  } else if constexpr (S == 2) {
+  int wofs[S == 1 ? 1 : NPF];
+  if constexpr (S == 2) {
 #pragma unroll
     for (int k = 0; k < NPF; ++k) {
       const int e = min(tid + k * NTHREADS, NE - 1);
-      const int v = e / NQ, yy = v / IX, xx = v % IX;
+      const int v = e / 4, yy = v / IX, xx = v % IX;
       wofs[k] = (tid + k * NTHREADS < NE)
-                    ? (yy * RP + (xx & 1) * 33 + (xx >> 1)) * PITCH + (e % NQ) * 8
-                    : (IY * RP) * PITCH + (tid & 3) * 8;       // the tail: spare voxels behind the image
+                    ? (yy * RP + (xx & 1) * 33 + (xx >> 1)) * PITCH + (e % 4) * 8
+                    : (C::IY * RP) * PITCH + (tid & 3) * 8;    // the tail: spare voxels behind the image
     }
   }
   // this lane's activation fragment: voxel (row (TM wave + m) S + dy, column r S + dx), half h
@@ -236,30 +292,21 @@ void conv_bf16x3_kernel(ConvParams p) {
   f32x16 acc[TM][NT];
   const unsigned lane16 = lane * 16u;
   static_assert(NITEM % AHEAD == 0, "continuous weight ring");
-  bf16x8 wq[AHEAD][NT][3];
-  unsigned half_a[3];                           // first channel pair of the element being split
+  frag wq[AHEAD][NT][NP];
+  unsigned half_a[NP];                          // first channel pair of the element being split
 
   // One element (4 channels of one voxel) -> image, split in two halves so that each rides in
-  // the gaps of one MFMA group.
+  // the gaps of one product group.
   auto convert = [&](auto kc, auto hc, unsigned char* img) {
     constexpr int k = decltype(kc)::value, half = decltype(hc)::value;
-    if constexpr (S3IN) {                       // a plain copy: the element is already split
-      *reinterpret_cast<f32x4*>(img + wofs[k]) = pf[k];
-      return;
-    }
-    float r0 = half ? pf[k].z : pf[k].x, r1 = half ? pf[k].w : pf[k].y;
-    unsigned pl[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      pl[q] = pack_bf16(r0, r1);
-      if (q < 2) { r0 -= bf16_lo(pl[q]); r1 -= bf16_hi(pl[q]); }
-    }
+    unsigned pl[NP];
+    split_pair<PM>(half ? pf[k].z : pf[k].x, half ? pf[k].w : pf[k].y, ss.sx, pl);
     if constexpr (half == 0) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) half_a[q] = pl[q];
+      for (int q = 0; q < NP; ++q) half_a[q] = pl[q];
     } else {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NP; ++q) {
         u32x2 v; v.x = half_a[q]; v.y = pl[q];
         if constexpr (S == 1) {
           if (!TWO || k < NPF - 1 || tid < NE - (NPF - 1) * NTHREADS)
@@ -275,13 +322,14 @@ void conv_bf16x3_kernel(ConvParams p) {
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < NP; ++q)
         wq[item % AHEAD][n][q] = __builtin_bit_cast(
-            bf16x8, buffer_load16(wrsrc, lane16, wb + ((item * NTP + n) * 3 + q) * (64 * 16)));
+            frag, buffer_load16(wrsrc, lane16, wb + ((item * NTP + n) * NPW + q) * (64 * 16)));
   };
 
   float* const aff = reinterpret_cast<float*>(lds_raw + 2 * IMG);
-  stage_affine_lds(aff, p.scale, p.shift, COUT, tid);        // visible after the loop's first barrier
+  stage_affine_lds(aff, p.scale, p.shift, COUT, tid, ss.out);   // visible after the loop's first barrier
+  float am = 0.f;                               // max |y| of this thread's outputs (y_amax)
   Pos cur_pos = tile_pos(t);
   tile_offsets(cur_pos);
   {                                             // first chunk of the launch: staged synchronously
@@ -292,7 +340,7 @@ void conv_bf16x3_kernel(ConvParams p) {
     static_for<0, AHEAD - 1>([&](auto ic) { wload(ic, wbase_of(cur_pos)); });
     static_for<0, NPF>([&](auto kc) {
       convert(kc, std::integral_constant<int, 0>{}, lds_raw);
-      if constexpr (!S3IN) convert(kc, std::integral_constant<int, 1>{}, lds_raw);
+      convert(kc, std::integral_constant<int, 1>{}, lds_raw);
     });
   }
   int cur = 0;                                  // image holding the current chunk
@@ -314,15 +362,15 @@ void conv_bf16x3_kernel(ConvParams p) {
           for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
     }
     const unsigned wchunk = wbase_of(cur_pos), wnext = nxt.t < end ? wbase_of(nxt) : wbase_of(cur_pos);
-    bf16x8 xq[2][3];
+    frag xq[2][NP];
     auto xload = [&](auto sc) {                 // s = item * TM + m
       constexpr int s = decltype(sc)::value;
       constexpr int item = s / TM, m = s % TM;
       constexpr int dy = (item / 3) * DIL, dx = (item % 3) * DIL;
       constexpr int vo = (S == 1) ? (m + dy) * RP + dx : (m * 2 + dy) * RP + (dx & 1) * 33 + (dx >> 1);
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
-        xq[s & 1][q] = *reinterpret_cast<const bf16x8*>(rd + vo * PITCH + q * 32);
+      for (int q = 0; q < NP; ++q)
+        xq[s & 1][q] = *reinterpret_cast<const frag*>(rd + vo * PITCH + q * 32);
     };
     DSM_STAMP(3);
     xload(std::integral_constant<int, 0>{});
@@ -347,28 +395,15 @@ void conv_bf16x3_kernel(ConvParams p) {
         });
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 xh = xq[s & 1][0], xm = xq[s & 1][1], xl = xq[s & 1][2];
+        // A operand = weights (rows: channels), B operand = activations (columns: voxels)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const bf16x8 wh = wq[item % AHEAD][n][0], wm = wq[item % AHEAD][n][1], wl = wq[item % AHEAD][n][2];
-          // A operand = weights (rows: channels), B operand = activations (columns: voxels);
-          // small terms first
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[m][n], 0, 0, 0);
-        }
+        for (int n = 0; n < NT; ++n) mma32<PM>(acc[m][n], wq[item % AHEAD][n], xq[s & 1]);
         // split half an element of the next chunk into the other image, in this group's gaps:
         // element j was requested in group j and is converted in groups CONV0 + 2j, + 2j + 1
 #if !(defined(DSM_ABLATE) && DSM_ABLATE == 1)
         static_for<0, CPG>([&](auto jc) {
-          constexpr int hidx = (s - CONV0) * CPG + decltype(jc)::value;   // half-element (S3: element) index
-          if constexpr (S3IN) {
-            if constexpr (s >= CONV0 && hidx < NPF)
-              convert(std::integral_constant<int, hidx>{}, std::integral_constant<int, 0>{}, nimg);
-          } else if constexpr (s >= CONV0 && hidx < 2 * NPF)
+          constexpr int hidx = (s - CONV0) * CPG + decltype(jc)::value;   // half-element index
+          if constexpr (s >= CONV0 && hidx < 2 * NPF)
             convert(std::integral_constant<int, hidx / 2>{}, std::integral_constant<int, hidx % 2>{}, nimg);
         });
 #endif
@@ -396,14 +431,14 @@ void conv_bf16x3_kernel(ConvParams p) {
           if (yo >= p.Ho || xo >= p.Wo) continue;
           const long vox = (((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo;
           const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
-          if (p.ys3)
+          if (PM == 3 && p.ys3)
             store_tile_s3<COUT>(acc[m][n], af, p.relu, p.y ? p.y + vox * COUT + cbase : nullptr,
                                 p.res ? p.res + rvox * COUT + cbase : nullptr,
                                 p.ys3 + (((((long)tb * p.Do + tz) * p.Ho + yo) * NTP + n0 + n) * 12) * p.Wo * 16,
-                                xo, p.Wo, h);
+                                xo, p.Wo, h, am);
           else
           store_tile<COUT>(acc[m][n], af, p.relu, p.y + vox * COUT + cbase,
-                           p.res ? p.res + rvox * COUT + cbase : nullptr);
+                           p.res ? p.res + rvox * COUT + cbase : nullptr, am);
         }
       }
     }
@@ -411,6 +446,7 @@ void conv_bf16x3_kernel(ConvParams p) {
     cur_pos = nxt; cur ^= 1;
     if (cur_pos.t >= end) break;
   }
+  flush_amax(p.y_amax, am, reinterpret_cast<float*>(lds_raw));
 }
 
 // ----------------------------------------------------------------------------
@@ -440,19 +476,32 @@ __host__ __device__ constexpr int dc_tap9(int j) {           // ky * 3 + kx of p
 #ifndef DSM_DECONV_WGS
 #define DSM_DECONV_WGS 2
 #endif
-template <int NT>
-__global__ __launch_bounds__(NTHREADS, NT == 1 ? DSM_DECONV_WGS : 1) void deconv_bf16x3_kernel(ConvParams p) {
-  constexpr int TY = 4, IY = TY + 1, IX = 33, CK = 32;
-  constexpr int NVOX = IY * IX;                 // 165
-  constexpr int NE = NVOX * 8;                  // 1320 staged 16-B fp32 quads per chunk
-  constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;   // 6
-  constexpr int PITCH = 208;                    // 2 k-groups x 3 planes x 32 B + 16 pad
-  constexpr int IMG = NPF * 32 * PITCH;         // 39,936 B
+template <int PM, int NT>
+struct DeconvSplitCfg {
+  static constexpr int NP = Prec<PM>::NP, NPW = Prec<PM>::NPW;
+  static constexpr int TY = 4, IY = TY + 1, IX = 33, CK = 32;
+  static constexpr int NVOX = IY * IX;                 // 165
+  static constexpr int NE = NVOX * 8;                  // 1320 staged 16-B fp32 quads per chunk
+  static constexpr int NPF = (NE + NTHREADS - 1) / NTHREADS;   // 6
+  static constexpr int PITCH = 2 * NP * 32 + 16;       // 2 k-groups x NP planes x 32 B + 16 pad
+  static constexpr int IMG = NPF * 32 * PITCH;         // 39,936 B (PM = 3)
+  static constexpr int COUT = 32 * NT;
+  static constexpr int LDS = 2 * IMG + 2 * COUT * 4;
+  // NT = 1 fits two workgroups per CU (PM = 3: 198 registers, 2 x 80 KB of LDS): the second one
+  // computes while the first one's four-class epilogue (stores, skip read) drains
+  static constexpr int WGS = NT == 1 ? DSM_DECONV_WGS : 1;
+};
+
+template <int PM, int NT>
+__global__ __launch_bounds__(NTHREADS, (DeconvSplitCfg<PM, NT>::WGS)) void deconv_split_kernel(ConvParams p) {
+  using C = DeconvSplitCfg<PM, NT>;
+  using frag = typename Prec<PM>::frag;
+  constexpr int NP = C::NP, NPW = C::NPW, TY = C::TY, IX = C::IX, CK = C::CK, NE = C::NE, NPF = C::NPF,
+                PITCH = C::PITCH, IMG = C::IMG, COUT = C::COUT;
   constexpr int NSTEP = 18;
   constexpr int AHEAD = 3;
   constexpr int CONV0 = NSTEP - 2 * NPF;        // 6
   constexpr unsigned OOBV = 0x80000000u;
-  constexpr int COUT = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -462,6 +511,7 @@ __global__ __launch_bounds__(NTHREADS, NT == 1 ? DSM_DECONV_WGS : 1) void deconv
   int step, end;
   int t = first_tile(p.ntiles, step, end);
   if (t >= end) return;
+  const SplitScale ss = split_scale<PM>(p);
 
   f32x4 pf[NPF];
   unsigned goff[NPF], yx[NPF], voff[NPF];
@@ -505,30 +555,25 @@ __global__ __launch_bounds__(NTHREADS, NT == 1 ? DSM_DECONV_WGS : 1) void deconv
   // weights [Cin/16][tap 27][n][plane][lane][16 B]; z-tap of this chunk: pz = 0 -> kz 1; pz = 1 -> kz 2, then 0
   auto wbase_of = [&](const Pos& q) {
     const int kz = q.pz ? (q.iz ? 0 : 2) : 1;
-    return (unsigned)((2 * q.ck * 27 + kz * 9) * NT) * (3 * 64 * 16);
+    return (unsigned)((2 * q.ck * 27 + kz * 9) * NT) * (NPW * 64 * 16);
   };
-  const int wr_off = (tid >> 3) * PITCH + ((tid & 7) >> 2) * 96 + (tid & 3) * 8;
+  const int wr_off = (tid >> 3) * PITCH + ((tid & 7) >> 2) * (NP * 32) + (tid & 3) * 8;
   const int rd_off = (wave * IX + r) * PITCH + h * 16;
 
   f32x16 acc[4][NT];
   const unsigned lane16 = lane * 16u;
-  bf16x8 wq[AHEAD][NT][3];
-  unsigned half_a[3];
+  frag wq[AHEAD][NT][NP];
+  unsigned half_a[NP];
   auto convert = [&](auto kc, auto hc, unsigned char* img) {
     constexpr int k = decltype(kc)::value, half = decltype(hc)::value;
-    float r0 = half ? pf[k].z : pf[k].x, r1 = half ? pf[k].w : pf[k].y;
-    unsigned pl[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      pl[q] = pack_bf16(r0, r1);
-      if (q < 2) { r0 -= bf16_lo(pl[q]); r1 -= bf16_hi(pl[q]); }
-    }
+    unsigned pl[NP];
+    split_pair<PM>(half ? pf[k].z : pf[k].x, half ? pf[k].w : pf[k].y, ss.sx, pl);
     if constexpr (half == 0) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) half_a[q] = pl[q];
+      for (int q = 0; q < NP; ++q) half_a[q] = pl[q];
     } else {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NP; ++q) {
         u32x2 v; v.x = half_a[q]; v.y = pl[q];
         *reinterpret_cast<u32x2*>(img + wr_off + k * (32 * PITCH) + q * 32) = v;
       }
@@ -541,13 +586,14 @@ __global__ __launch_bounds__(NTHREADS, NT == 1 ? DSM_DECONV_WGS : 1) void deconv
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < NP; ++q)
         wq[s % AHEAD][n][q] = __builtin_bit_cast(
-            bf16x8, buffer_load16(wrsrc, lane16, wb + (((g * 27 + tap9) * NT + n) * 3 + q) * (64 * 16)));
+            frag, buffer_load16(wrsrc, lane16, wb + (((g * 27 + tap9) * NT + n) * NPW + q) * (64 * 16)));
   };
 
   float* const aff = reinterpret_cast<float*>(lds_raw + 2 * IMG);
-  stage_affine_lds(aff, p.scale, p.shift, COUT, tid);
+  stage_affine_lds(aff, p.scale, p.shift, COUT, tid, ss.out);
+  float am = 0.f;
   Pos cur_pos = item_pos(t);
   item_offsets(cur_pos);
   {
@@ -579,14 +625,14 @@ __global__ __launch_bounds__(NTHREADS, NT == 1 ? DSM_DECONV_WGS : 1) void deconv
           for (int i = 0; i < 16; ++i) acc[c][n][i] = 0.f;
     }
     const unsigned wchunk = wbase_of(cur_pos), wnext = nxt.t < end ? wbase_of(nxt) : 0u;
-    bf16x8 xq[2][3];
+    frag xq[2][NP];
     // activation fragment set xi = g * 4 + o (k-group, input offset)
     auto xload = [&](auto xc) {
       constexpr int xi = decltype(xc)::value;
       constexpr int g = xi / 4, o = xi % 4, iy = o >> 1, ix = o & 1;
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
-        xq[xi & 1][q] = *reinterpret_cast<const bf16x8*>(rd + (iy * IX + ix) * PITCH + (g * 3 + q) * 32);
+      for (int q = 0; q < NP; ++q)
+        xq[xi & 1][q] = *reinterpret_cast<const frag*>(rd + (iy * IX + ix) * PITCH + (g * NP + q) * 32);
     };
     xload(std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -601,18 +647,8 @@ __global__ __launch_bounds__(NTHREADS, NT == 1 ? DSM_DECONV_WGS : 1) void deconv
       if constexpr (fresh && xi + 1 < 8) xload(std::integral_constant<int, xi + 1>{});
       if constexpr (s < NPF) pf[s] = buffer_load16(nrsrc, voff[s], 0);
       __builtin_amdgcn_sched_barrier(0);
-      const bf16x8 xh = xq[xi & 1][0], xm = xq[xi & 1][1], xl = xq[xi & 1][2];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const bf16x8 wh = wq[s % AHEAD][n][0], wm = wq[s % AHEAD][n][1], wl = wq[s % AHEAD][n][2];
-        f32x16& a = acc[pr.c][n];
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, a, 0, 0, 0);
-      }
+      for (int n = 0; n < NT; ++n) mma32<PM>(acc[pr.c][n], wq[s % AHEAD][n], xq[xi & 1]);
       if constexpr (s >= CONV0)
         convert(std::integral_constant<int, (s - CONV0) / 2>{},
                 std::integral_constant<int, (s - CONV0) % 2>{}, nimg);
@@ -632,14 +668,14 @@ __global__ __launch_bounds__(NTHREADS, NT == 1 ? DSM_DECONV_WGS : 1) void deconv
             if (yo >= p.Ho || xo >= p.Wo) continue;
             const long vox = (((long)cur_pos.b * p.Do + zo) * p.Ho + yo) * p.Wo + xo;
             const long rvox = (((long)cur_pos.b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo;
-            if (p.ys3)
+            if (PM == 3 && p.ys3)
               store_tile_s3<COUT>(acc[c][n], af, p.relu, p.y ? p.y + vox * COUT + cbase : nullptr,
                                   p.res ? p.res + rvox * COUT + cbase : nullptr,
                                   p.ys3 + (((((long)cur_pos.b * p.Do + zo) * p.Ho + yo) * NT + n) * 12) * p.Wo * 16,
-                                  xo, p.Wo, h);
+                                  xo, p.Wo, h, am);
             else
             store_tile<COUT>(acc[c][n], af, p.relu, p.y + vox * COUT + cbase,
-                             p.res ? p.res + rvox * COUT + cbase : nullptr);
+                             p.res ? p.res + rvox * COUT + cbase : nullptr, am);
           }
         }
       }
@@ -647,14 +683,17 @@ __global__ __launch_bounds__(NTHREADS, NT == 1 ? DSM_DECONV_WGS : 1) void deconv
     cur_pos = nxt; cur ^= 1;
     if (cur_pos.t >= end) break;
   }
+  flush_amax(p.y_amax, am, reinterpret_cast<float*>(lds_raw));
 }
 
-// weights -> section 2 of the packed buffer: [Cin/16][tap][Cout/32][plane][lane][8 bf16],
-// tap = dz * 9 + t9 (ntaps = 27) or t9 (ntaps = 9)
-// s3order: input channels in the k-slot order of an S3-input kernel (see conv_bf16x3_kernel)
-__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                           int Cin, int Cout, int transposed, int ntaps, int cin_src,
-                                           int s3order) {
+// weights -> the split section of a packed buffer: [Cin/16][tap][Cout/32][plane NPW][lane][8 x 16-bit],
+// tap = dz * 9 + t9 (ntaps = 27) or t9 (ntaps = 9).  PM = 3: three bf16 planes; PM = 2: two fp16
+// planes of w * 2^ew, ew from the header's absolute maximum (`w_amax`, written by absmax_kernel).
+template <int PM>
+__global__ void pack_weights_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                          const float* __restrict__ w_amax, int Cin, int Cout,
+                                          int transposed, int ntaps, int cin_src) {
+  constexpr int NPW = Prec<PM>::NPW;
   const long n = (long)Cin * Cout * ntaps;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
@@ -664,18 +703,70 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned
   const int lane = i & 63; i >>= 6;
   const int n_ = i % NT; i /= NT;
   const int tap = i % ntaps; const int c16 = i / ntaps;
-  const int cin = s3order ? 32 * (c16 >> 1) + 16 * (j >> 2) + 4 * (2 * (c16 & 1) + (lane >> 5)) + (j & 3)
-                          : 16 * c16 + 8 * (lane >> 5) + j;
+  const int cin = 16 * c16 + 8 * (lane >> 5) + j;
   const int cout = 32 * n_ + (lane & 31);
   const long src = transposed ? (((long)cin * Cout + cout) * ntaps + tap)
                               : (((long)cout * cin_src + cin) * ntaps + tap);
-  float v = cin < cin_src ? w[src] : 0.f;
-  unsigned short* o = out + (((((long)c16 * ntaps + tap) * NT + n_) * 3) * 64 + lane) * 8 + j;
+  const float v = cin < cin_src ? w[src] : 0.f;
+  unsigned short* o = out + (((((long)c16 * ntaps + tap) * NT + n_) * NPW) * 64 + lane) * 8 + j;
+  unsigned pl[NPW];
+  split_pair<(PM == 3 ? 3 : 2)>(v, 0.f, PM == 3 ? 1.f : dsm_pow2f(dsm_amax_exponent(*w_amax)), pl);
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const unsigned u = pack_bf16(v, 0.f);
-    o[(long)q * 64 * 8] = (unsigned short)(u & 0xffffu);
-    v -= bf16_lo(u);
-  }
+  for (int q = 0; q < NPW; ++q) o[(long)q * 64 * 8] = (unsigned short)(pl[q] & 0xffffu);
 }
 
+// absolute maximum of a buffer into *out (atomic max of the float bits; *out zeroed by the caller)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+  float am = 0.f;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+    track_amax(am, reinterpret_cast<const f32x4*>(x)[i]);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) am = fmaxf(am, fabsf(x[(n4 << 2) + threadIdx.x]));
+  __shared__ float red[4];
+  flush_amax(out, am, red);
+}
+
+// ---------------------------------------------------------------------------- launch helpers
+template <int PM, int NT, int TM, int KZ, int DIL, int S = 1, int NSPLIT = 1>
+int run_conv_split(ConvParams p, hipStream_t s) {
+  using C = ConvSplitCfg<PM, NT, TM, KZ, DIL, S, NSPLIT>;
+  p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, C::TY);
+  const long nt = (long)p.B * p.Do * p.nty * p.ntx;
+  if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
+  p.ntiles = (int)nt;
+  // two images; one workgroup per CU, or two where conv_split_two_per_cu says both fit
+  return launch_tiles(conv_split_kernel<PM, NT, TM, KZ, DIL, S, NSPLIT>, p, C::LDS, s,
+                      (C::TWO ? 512 : 256) / NSPLIT, NSPLIT);
+}
+
+template <int PM, int NT>
+int run_deconv_split(ConvParams p, hipStream_t s) {
+  using C = DeconvSplitCfg<PM, NT>;
+  p.ntx = dsm_cdiv(p.Wi, 32); p.nty = dsm_cdiv(p.Hi, 4);
+  const long nt = (long)p.B * p.Di * p.nty * p.ntx * 2;       // x2: z-parity
+  if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
+  p.ntiles = (int)nt;
+  return launch_tiles(deconv_split_kernel<PM, NT>, p, C::LDS, s, 256 * C::WGS);
+}
+
+// plan kinds 5 (convolution) and 6 (transposed convolution) at precision mode PM
+template <int PM>
+int dispatch_split(const Plan& pl, const ConvParams& p, hipStream_t s) {
+  if (pl.kind == 6) return pl.NT == 1 ? run_deconv_split<PM, 1>(p, s) : run_deconv_split<PM, 2>(p, s);
+  if (pl.kind != 5) return DSM_ERR_UNSUPPORTED;
+  if (pl.S == 2) return run_conv_split<PM, 2, 1, 3, 1, 2>(p, s);
+  if (pl.nsplit == 2) {                         // 2-D layers of 64 / 128 channels in two workgroup columns
+    if (pl.KZ == 1 && pl.NT == 1 && pl.TM == 2 && pl.DIL == 1) return run_conv_split<PM, 1, 2, 1, 1, 1, 2>(p, s);
+    if (pl.KZ == 1 && pl.NT == 2 && pl.TM == 2 && pl.DIL == 1) return run_conv_split<PM, 2, 2, 1, 1, 1, 2>(p, s);
+    if (pl.KZ == 3 && pl.NT == 1 && pl.TM == 1) return run_conv_split<PM, 1, 1, 3, 1, 1, 2>(p, s);
+    return DSM_ERR_UNSUPPORTED;
+  }
+#define DSM_CASE_SPLIT(NT_, TM_, KZ_, DIL_) \
+  if (pl.NT == NT_ && pl.TM == TM_ && pl.KZ == KZ_ && pl.DIL == DIL_) return run_conv_split<PM, NT_, TM_, KZ_, DIL_>(p, s)
+  DSM_CASE_SPLIT(1, 4, 3, 1); DSM_CASE_SPLIT(1, 2, 3, 1); DSM_CASE_SPLIT(2, 2, 3, 1); DSM_CASE_SPLIT(2, 1, 3, 1);
+  DSM_CASE_SPLIT(1, 4, 1, 1); DSM_CASE_SPLIT(1, 2, 1, 1); DSM_CASE_SPLIT(2, 2, 1, 1); DSM_CASE_SPLIT(2, 1, 1, 1);
+  DSM_CASE_SPLIT(4, 2, 1, 1);
+  DSM_CASE_SPLIT(4, 2, 1, 2);
+#undef DSM_CASE_SPLIT
+  return DSM_ERR_UNSUPPORTED;
+}

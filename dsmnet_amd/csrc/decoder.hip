@@ -88,81 +88,7 @@ __global__ __launch_bounds__(256) void stage_pair_kernel(const float* __restrict
   for (int q = 0; q < 4; ++q) dst[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
 }
 
-// PSMNet's first tower layer on the raw images: Conv2d(3 -> 32, k3, stride 2, pad 1) + folded BN +
-// ReLU (models/psmnet/submodule.py:70-72), both views in one launch, NCHW images in, NHWC 32-channel
-// map out.  27 x 32 MACs per output pixel on the VALU (v_pk_fma_f32: the tap's 32 weights as SGPR
-// pairs, the input value broadcast), instead of staging the images to 16 NHWC channels (63 MB
-// written and read back at 384 x 1280) for the MFMA kernel: one launch replaces two.
-// wt: [27 taps (c, ky, kx)][32 couts].  Thread = one output pixel.
-__global__ __launch_bounds__(256) void conv_first3_kernel(const float* __restrict__ left,
-                                                          const float* __restrict__ right,
-                                                          const float* __restrict__ wt,
-                                                          const float* __restrict__ scale,
-                                                          const float* __restrict__ shift,
-                                                          float* __restrict__ out, int B, int H, int W,
-                                                          int Ho, int Wo, int relu) {
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  typedef const float __attribute__((address_space(4))) cfloat;
-  typedef f32x4 __attribute__((address_space(4))) cquad;
-  const long n = (long)(right ? 2 * B : B) * Ho * Wo;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho), b = (int)(i / ((long)Wo * Ho));
-  const float* img = b < B ? left + (long)b * 3 * H * W : right + (long)(b - B) * 3 * H * W;
-  cfloat* wc = (cfloat*)wt;
-  asm volatile("" : "+s"(wc));                         // keep the weight loads inside the tap loop
-  f2 acc[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) acc[k] = f2{0.f, 0.f};
-  float in[27];                                        // all 27 inputs first: one round of load latency
-#pragma unroll
-  for (int tap = 0; tap < 27; ++tap) {
-    const int c = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-    const int yi = 2 * yo - 1 + ky, xi = 2 * xo - 1 + kx;
-    in[tap] = (yi >= 0 && yi < H && xi >= 0 && xi < W) ? img[((long)c * H + yi) * W + xi] : 0.f;
-  }
-#pragma unroll
-  for (int tap = 0; tap < 27; ++tap) {
-    const float a = in[tap];
-    f32x4 w4[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) w4[q] = *(const volatile cquad*)(wc + tap * 32 + q * 4);
-    const f2 a2 = {a, a};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      acc[2 * q] = __builtin_elementwise_fma(a2, f2{w4[q].x, w4[q].y}, acc[2 * q]);
-      acc[2 * q + 1] = __builtin_elementwise_fma(a2, f2{w4[q].z, w4[q].w}, acc[2 * q + 1]);
-    }
-    __builtin_amdgcn_sched_barrier(0);                 // one tap's 32 SGPRs live at a time
-  }
-  f32x4* dst = reinterpret_cast<f32x4*>(out + i * 32);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    f32x4 v = {acc[2 * q].x, acc[2 * q].y, acc[2 * q + 1].x, acc[2 * q + 1].y};
-    if (scale) v = v * *reinterpret_cast<const f32x4*>(scale + 4 * q);
-    if (shift) v = v + *reinterpret_cast<const f32x4*>(shift + 4 * q);
-    if (relu) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-    dst[q] = v;
-  }
-}
-
 }  // namespace
-
-extern "C" int dsm_conv2d_first3_fwd(const void* left, const void* right, const void* w_taps,
-                                     const float* scale, const float* shift, void* out, int B, int H,
-                                     int W, int relu, dsm_stream_t stream) {
-  DSM_REQUIRE(left && w_taps && out && B > 0 && H > 0 && W > 0, DSM_ERR_ARG);
-  DSM_REQUIRE(dsm_aligned16(out) && dsm_aligned16(w_taps) && dsm_aligned16(scale) && dsm_aligned16(shift),
-              DSM_ERR_ALIGN);
-  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const long n = (long)(right ? 2 : 1) * B * Ho * Wo;
-  DSM_REQUIRE(n / 256 < 0x7fffffffL, DSM_ERR_UNSUPPORTED);
-  dsm_clear_stale_error();
-  hipLaunchKernelGGL(conv_first3_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)left, (const float*)right, (const float*)w_taps, scale, shift,
-                     (float*)out, B, H, W, Ho, Wo, relu ? 1 : 0);
-  return dsm_launch_status();
-}
 
 extern "C" int dsm_stage_images_nhwc16(const void* left, const void* right, void* out, int B, int C,
                                        int H, int W, dsm_stream_t stream) {

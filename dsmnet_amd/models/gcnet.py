@@ -99,9 +99,13 @@ class gcnet(nn.Module):
         if self.training:
             return self.layer2d(imL), self.layer2d(imR)
         both = self.layer2d(torch.cat([imL, imR], dim=0))     # eval: BN uses running stats
-        return both[: imL.shape[0]], both[imL.shape[0]:]
+        return cv.carry_amax(both[: imL.shape[0]], both), cv.carry_amax(both[imL.shape[0]:], both)
 
     def forward(self, imL, imR, mode="train"):
+        with cv.amax_scope(imL.device):
+            return self._forward(imL, imR, mode)
+
+    def _forward(self, imL, imR, mode):
         if imL.shape != imR.shape:
             raise ValueError("gcnet: imL and imR must have the same shape")   # gcnet.py:127
         fL, fR = self.features(imL, imR)

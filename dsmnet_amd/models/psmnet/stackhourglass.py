@@ -43,21 +43,12 @@ class hourglass(nn.Module):
     def forward(self, x, presqu, postsqu, skip=None, out_format="f32"):
         """Reference signature plus ``skip``: when given, ``out + skip`` (the caller's
         ``myadd_3d(out, cost0)``, stackhourglass.py:139-145) is fused into conv6;
-        ``out_format`` ("f32" | "both"): the format(s) conv6 writes ``out`` in (eval only)."""
-        if out_format == "f32" or not isinstance(x, cv.S3Volume):  # training / autograd / fp32 hand-over
-            out = self.conv1(x)                                    # 1/4 -> 1/8
-            pre = self.conv2(out, residual=postsqu, relu=True)     # relu(conv2 (+ postsqu))
-            out = self.conv4(self.conv3(pre))                      # 1/8 -> 1/16
-            post = self.conv5(out, residual=presqu if presqu is not None else pre, relu=True)
-            return self.conv6(post, residual=skip, out=out_format), pre, post      # 1/8 -> 1/4
-        # eval: `x` is an S3Volume; every convolution hands its result to the next one pre-split
-        # (".s"); fp32 copies (".f") only where a skip addition or a transposed convolution reads it
-        out_s = self.conv1(x, out="s3")
-        pre_f, pre_s = self.conv2(out_s, residual=postsqu, relu=True, out="both")
-        out_f = self.conv4(self.conv3(pre_s, out="s3"))
-        post = self.conv5(out_f, residual=presqu if presqu is not None else pre_f, relu=True)
-        out = self.conv6(post, residual=skip, out=out_format)
-        return out, pre_f, post
+        ``out_format`` ("f32" | "s3" | "both"): the format(s) conv6 writes ``out`` in (eval, bf16x3)."""
+        out = self.conv1(x)                                    # 1/4 -> 1/8
+        pre = self.conv2(out, residual=postsqu, relu=True)     # relu(conv2 (+ postsqu))
+        out = self.conv4(self.conv3(pre))                      # 1/8 -> 1/16
+        post = self.conv5(out, residual=presqu if presqu is not None else pre, relu=True)
+        return self.conv6(post, residual=skip, out=out_format), pre, post      # 1/8 -> 1/4
 
 
 class PSMNet(nn.Module):
@@ -105,15 +96,12 @@ class PSMNet(nn.Module):
             return self.feature_extraction(left), self.feature_extraction(right)
         # eval: BN uses running statistics, so both views can share one batch
         fe = self.feature_extraction
-        if left.is_cuda and not torch.is_grad_enabled() and fe.first_layer_fusable(left) and not cv.get_option("s3in"):
-            # the first layer of both views straight from the raw images, one launch
-            both = fe(left, first=fe.first_layer_of_pair(left, right))
-        elif left.is_cuda and not torch.is_grad_enabled() and left.shape[1] <= 16:
+        if left.is_cuda and not torch.is_grad_enabled() and left.shape[1] <= 16:
             # concatenation + NHWC staging (3 -> 16 channels) in one launch
             both = fe(cv.stage_images_nhwc16(left, right), staged=True)
         else:
             both = self.feature_extraction(torch.cat([left, right], dim=0))
-        return both[: left.shape[0]], both[left.shape[0]:]
+        return (cv.carry_amax(both[: left.shape[0]], both), cv.carry_amax(both[left.shape[0]:], both))
 
     def _s3_path(self):
         """Eval mode without autograd: the 32-channel full-resolution layers (dres0, dres1,
@@ -138,50 +126,20 @@ class PSMNet(nn.Module):
         # same dataflow; tensors that feed an S3 layer travel as S3 (".s"), those that feed the
         # fp32 kernels (stride-2 convolutions, skip additions) as fp32 (".f")
         c0a_f, c0a_s = self.dres0(cost, out="both")
-        if cv.get_option("s3in"):              # the hourglasses read S3 too (off by default: slower)
-            cost0, cost0_s = self.dres1(c0a_s, residual=c0a_f, out="both")
-            o1_s, pre1, post1 = self.dres2(cost0_s, None, None, skip=cost0, out_format="s3")
-            o2_s, pre2, post2 = self.dres3(o1_s, pre1, post1, skip=cost0, out_format="s3")
-            o3_s, pre3, post3 = self.dres4(o2_s, pre1, post2, skip=cost0, out_format="s3")
-        else:
-            cost0 = self.dres1(c0a_s, residual=c0a_f)
-            (o1_f, o1_s), pre1, post1 = self.dres2(cost0, None, None, skip=cost0, out_format="both")
-            (o2_f, o2_s), pre2, post2 = self.dres3(o1_f, pre1, post1, skip=cost0, out_format="both")
-            o3_s, pre3, post3 = self.dres4(o2_f, pre1, post2, skip=cost0, out_format="s3")
+        cost0 = self.dres1(c0a_s, residual=c0a_f)
+        (o1_f, o1_s), pre1, post1 = self.dres2(cost0, None, None, skip=cost0, out_format="both")
+        (o2_f, o2_s), pre2, post2 = self.dres3(o1_f, pre1, post1, skip=cost0, out_format="both")
+        o3_s, pre3, post3 = self.dres4(o2_f, pre1, post2, skip=cost0, out_format="s3")
         cost1 = self.classif1(o1_s)
         cost2 = self.classif2(o2_s, residual=cost1)
         cost3 = self.classif3(o3_s, residual=cost2)
         return cost1, cost2, cost3
 
-    def _heads_beside_the_trunk(self, cost, size):
-        """The S3 eval dataflow of ``regularise`` + the three heads with classif1 / classif2 and their
-        soft-argmin on a second stream: they depend on out1 / out2 only, the next hourglass does not
-        depend on them (stackhourglass.py:146-166), and several of its kernels leave CUs idle (the
-        12 x 24 x 80 layers launch 108-216 workgroups).  Fork / join with events; under
-        ``torch.cuda.graph`` both branches are captured."""
-        main = torch.cuda.current_stream()
-        side = self.__dict__.get("_side_stream")
-        if side is None or side.device != cost.device:
-            side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=cost.device)
-        sa = lambda c: cv.soft_argmin(c, size, align_corners=self.align_corners)
-        c0a_f, c0a_s = self.dres0(cost, out="both")
-        cost0 = self.dres1(c0a_s, residual=c0a_f)
-        (o1_f, o1_s), pre1, post1 = self.dres2(cost0, None, None, skip=cost0, out_format="both")
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            cost1 = self.classif1(o1_s)
-            pred1 = sa(cost1)
-        (o2_f, o2_s), pre2, post2 = self.dres3(o1_f, pre1, post1, skip=cost0, out_format="both")
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            cost2 = self.classif2(o2_s, residual=cost1)
-            pred2 = sa(cost2)
-        o3_s, pre3, post3 = self.dres4(o2_f, pre1, post2, skip=cost0, out_format="s3")
-        main.wait_stream(side)
-        pred3 = sa(self.classif3(o3_s, residual=cost2))
-        return pred1, pred2, pred3
-
     def forward(self, left, right, mode="train"):
+        with cv.amax_scope(left.device):
+            return self._forward(left, right)
+
+    def _forward(self, left, right):
         refimg_fea, targetimg_fea = self.features(left, right)
         if self._s3_path() and cv.get_option("fuse_volume"):
             # the volume is never written: dres0's first convolution stages it from the split
@@ -191,9 +149,6 @@ class PSMNet(nn.Module):
         else:
             cost = cv.concat_volume(refimg_fea, targetimg_fea, self.maxdisp // 4, mask_left=True)
         size = (self.maxdisp, left.shape[2], left.shape[3])
-        if self._s3_path() and cv.get_option("overlap_heads") and not cv.get_option("s3in"):
-            pred1, pred2, pred3 = self._heads_beside_the_trunk(cost, size)
-            return [0, 0, 0], [pred3, pred2, pred1]
         cost1, cost2, cost3 = self.regularise(cost)
         pred1 = cv.soft_argmin(cost1, size, align_corners=self.align_corners)
         pred2 = cv.soft_argmin(cost2, size, align_corners=self.align_corners)

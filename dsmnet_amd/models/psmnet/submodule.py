@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import costvolume as cv
-from ...blocks2d import ConvBN2d, _Folded2d, run_conv2d, s3in_ok, s3out_ok, stage_image_nhwc16
+from ...blocks2d import ConvBN2d, _Folded2d, run_conv2d, stage_image_nhwc16
 from ...blocks3d import ConvBN3d, _versions
 
 # DSM_TRAIN_SPP=interp (read by this host module) keeps F.interpolate under autograd (A/B runs)
@@ -51,19 +51,6 @@ class BasicBlock(nn.Module):
         y = self.conv1[0](x, relu=True)                    # convbn + the Sequential's ReLU
         skip = x if self.downsample is None else self.downsample(x)
         return self.conv2(y, residual=skip)                # convbn + skip add, no ReLU after
-
-    def forward_s3(self, x_f, x_s, want_s3):
-        """Eval fast path: ``x_f`` the block's input as an fp32 map (skip addition, 1x1 / stride-2
-        layers), ``x_s`` the same map as an S3Volume or None; activations between two bf16x3
-        convolutions travel pre-split (csrc/conv_s3.hip: S3).  Returns (out_f, out_s or None)."""
-        c1, c2 = self.conv1[0], self.conv2
-        x1 = x_s if (x_s is not None and s3in_ok(c1[0])) else x_f
-        mid_s3 = s3in_ok(c2[0]) and s3out_ok(c1[0])
-        y = c1(x1, relu=True, out="s3" if mid_s3 else "f32")
-        skip = x_f if self.downsample is None else self.downsample(x_f)
-        if want_s3 and s3out_ok(c2[0]):
-            return c2(y, residual=skip, out="both")
-        return c2(y, residual=skip), None
 
 
 class disparityregression(nn.Module):
@@ -182,69 +169,21 @@ class feature_extraction(nn.Module):
             self._spp_key = key
         return self._spp_cache
 
-    def _trunk_s3(self, x, staged=False):
-        """firstconv .. layer4 in eval mode with S3 hand-over between the bf16x3 convolutions.
-        Returns (raw, skip) as fp32 maps."""
-        x = self.firstconv[0](x if staged else stage_image_nhwc16(x), relu=True)    # 3 -> 32, stride 2: fp32-input MFMA
-        x_s = self.firstconv[2](x, relu=True, out="s3")
-        x_f, x_s = self.firstconv[4](x_s, relu=True, out="both")
-        blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
-        raw = None
-        for i, b in enumerate(blocks):
-            last = i + 1 == len(blocks)
-            x_f, x_s = b.forward_s3(x_f, x_s, want_s3=not last)
-            if b is self.layer2[-1]:
-                raw = x_f
-        return raw, x_f
-
-    def first_layer_of_pair(self, left, right=None):
-        """Eval fast path: firstconv[0] + BN + ReLU of both views straight from the raw NCHW images
-        (``costvolume.conv2d_first3``: one VALU launch instead of NHWC staging + the MFMA kernel).
-        Returns the (2B or B, 32, H/2, W/2) channels_last map for ``forward(..., first=...)``."""
-        conv, bn = self.firstconv[0][0], self.firstconv[0][1]
-        srcs = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-        key = _versions(*srcs)
-        if self.__dict__.get("_first_key") != key:
-            with torch.no_grad():
-                inv = torch.rsqrt(bn.running_var + bn.eps)
-                scale = (bn.weight * inv).contiguous()
-                shift = (bn.bias - bn.running_mean * scale).contiguous()
-                w_taps = conv.weight.reshape(32, 27).t().contiguous()
-            self.__dict__["_first_cache"] = (w_taps, scale, shift)
-            self.__dict__["_first_key"] = key
-        w_taps, scale, shift = self.__dict__["_first_cache"]
-        return cv.conv2d_first3(left, right, w_taps, scale, shift, relu=True)
-
-    def first_layer_fusable(self, x):
-        conv = self.firstconv[0][0]
-        return (x.is_cuda and x.dtype == torch.float32 and not self.training and not torch.is_grad_enabled()
-                and x.shape[1] == 3 and conv.in_channels == 3 and conv.out_channels == 32 and
-                conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and
-                conv.dilation == (1, 1) and conv.bias is None and cv.get_option("first3"))
-
-    def forward(self, x, staged=False, first=None):
+    def forward(self, x, staged=False):
         """``staged``: ``x`` is already the (B,16,H,W) NHWC staging of the image(s)
-        (``costvolume.stage_images_nhwc16``); ``first``: the output of ``first_layer_of_pair`` (``x`` is
-        then ignored).  Both on the eval fast path only."""
-        fast = (x if first is None else first).is_cuda and not self.training and not torch.is_grad_enabled()
-        if (staged or first is not None) and not fast:
+        (``costvolume.stage_images_nhwc16``) -- eval fast path only."""
+        fast = x.is_cuda and not self.training and not torch.is_grad_enabled()
+        if staged and not fast:
             raise RuntimeError("feature_extraction: staged input exists on the eval fast path only")
-        if first is None and fast and not staged and self.first_layer_fusable(x):
-            first = self.first_layer_of_pair(x)
-        if first is None and fast and cv.get_option("s3") and cv.get_option("s3in") and cv.get_option_bf16x3():
-            raw, skip = self._trunk_s3(x, staged)
-        else:
-            if first is not None:
-                x = first
-            elif fast and not staged:
-                x = stage_image_nhwc16(x)                  # NHWC, 3 -> 16 staged channels
-            elif _TRAIN_NHWC and x.is_cuda:
-                x = x.contiguous(memory_format=torch.channels_last)
-            for i in ((2, 4) if first is not None else (0, 2, 4)):
-                x = self.firstconv[i](x, relu=True)
-            x = self.layer1(x)
-            raw = self.layer2(x)
-            skip = self.layer4(self.layer3(raw))
+        if fast and not staged:
+            x = stage_image_nhwc16(x)                  # NHWC, 3 -> 16 staged channels
+        elif _TRAIN_NHWC and x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
+        for i in (0, 2, 4):
+            x = self.firstconv[i](x, relu=True)
+        x = self.layer1(x)
+        raw = self.layer2(x)
+        skip = self.layer4(self.layer3(raw))
         if skip.is_cuda and not self.training and not torch.is_grad_enabled() and not self.align_corners:
             x = cv.spp_head(raw, skip, *self._spp_params())       # three launches (csrc/spp.hip)
         else:

@@ -14,8 +14,10 @@
  *    (a hipStream_t passed as void*; NULL = the null stream);
  *  - return value: DSM_OK (0) or a negative DSM_ERR_* code; no exceptions
  *    cross the boundary; dsm_strerror() names a code;
- *  - dtype: only DSM_F32 is implemented (the reference computes in fp32:
- *    torch.FloatTensor, models/psmnet/stackhourglass.py:124);
+ *  - dtype: tensors are fp32 (DSM_F32; the reference computes in fp32: torch.FloatTensor,
+ *    models/psmnet/stackhourglass.py:124).  What the convolutions MULTIPLY in is a per-call choice,
+ *    dsm_conv3d_args.precision (DSM_PREC_*): fp32-accurate (default), or operands rounded to fp16
+ *    with fp32 accumulation -- the reduced-precision mode of BASELINE config #5;
  *  - 4-D feature maps are NCHW contiguous, as torch hands them over;
  *  - 5-D volumes are either DSM_NCDHW (torch contiguous) or DSM_NDHWC
  *    (torch.channels_last_3d), selected per call.
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DSM_ABI_VERSION 5
+#define DSM_ABI_VERSION 6
 
 #define DSM_OK               0
 #define DSM_ERR_ARG         -1   /* null pointer, non-positive size, bad enum      */
@@ -151,15 +153,31 @@ typedef struct dsm_conv3d_args {
    * dsm_conv3d_s3_fwd; `y` may then be NULL.  Only the bf16x3 3-D kernels have this epilogue
    * (Conv3d / ConvTranspose3d with Cout in {32, 64}); DSM_ERR_UNSUPPORTED otherwise. */
   void*        y_s3;
-  /* ABI v4: the input in the S3 format instead of `x` (which is then NULL): Conv3d / Conv2d
-   * (not transposed) on the bf16x3 kernels, Cin % 32 == 0, w_packed from
-   * dsm_conv_pack_weights_s3in.  The operand split then happened once, in the producer's
-   * epilogue, and the kernel's staging is a plain copy. */
-  const void*  x_s3;
   /* ABI v4: tuning / A-B switches of THIS call (0 = the plan's own choice).  The library reads no
    * environment variable and holds no global switch: a plan is a pure function of the arguments. */
   int          flags;
+  /* ABI v6: what the 3x3(x3) MFMA kernels multiply in (DSM_PREC_*, below).  The fp16 modes scale
+   * every tensor by a power of two taken from its absolute maximum: `x_amax` points at a device
+   * float holding max |x| (or an upper bound of it) -- written by the launch that produced x
+   * through ITS y_amax, or by dsm_absmax; required when precision != DSM_PREC_F32 and the layer runs
+   * on a split kernel (dsm_conv3d_plan names it "..._f16x2_..." / "..._f16_..."), ignored otherwise. */
+  int          precision;
+  const float* x_amax;
+  /* ABI v6: optional.  max |y| of this launch is folded into *y_amax with an atomic maximum on the
+   * float bits: the caller zeroes it (on the stream) before the launch.  Any precision, every MFMA
+   * kernel (Cout >= 32). */
+  float*       y_amax;
 } dsm_conv3d_args;
+/* fp32 operands, fp32-accurate products and sums: three-term bf16 split (six bf16 MFMAs per
+ * product) or, with DSM_CONV_FP32_MFMA, the fp32-input MFMA */
+#define DSM_PREC_F32    0
+/* operands rounded to fp16 (after the power-of-two scaling), one MFMA per product, fp32 accumulate:
+ * relative error ~3e-4 of the result's scale.  BASELINE config #5 ("fp16 training step"). */
+#define DSM_PREC_F16    1
+/* fp32 accuracy on the fp16 pipe: x * 2^e = hi + lo in fp16 (22 significand bits), three MFMAs per
+ * product (wl xh + wh xl + wh xh), fp32 accumulate; measured error vs float64 at or below the
+ * bf16x3 and fp32-input kernels' (scripts/precision_check.py). */
+#define DSM_PREC_F16X2  2
 #define DSM_CONV_FP32_MFMA      0x1      /* keep the layer on the exact fp32-input MFMA (no bf16x3)   */
 #define DSM_CONV_COUT1_CHUNKED  0x2      /* Cout = 1: the chunked kernel instead of the z-sliding one */
 #define DSM_CONV_NO_NSPLIT      0x4      /* 2-D bf16x3 layers: one workgroup per tile (no N-split)    */
@@ -176,15 +194,15 @@ int dsm_conv3d_pack_weights(const void* w_torch, void* w_packed,
 /* General packer: kd x k x k taps, torch layout (Cout, Cin_src, [kd,] k, k); input channels
  * Cin_src..Cin-1 are packed as zeros (PSMNet's first convolution: 3 staged as 16).
  * Bytes needed: dsm_conv_packed_weight_bytes (the fp32 fragments, Cin*Cout*kd*k*k*4, followed for
- * 3x3(x3) kernels by the pre-split bf16 planes the bf16x3 kernels read). */
+ * 3x3(x3) kernels by the pre-split bf16 planes the bf16x3 kernels read and by the two fp16 planes
+ * of the power-of-two-scaled weights behind a 16-byte header holding their absolute maximum). */
 size_t dsm_conv_packed_weight_bytes(int Cin, int Cout, int kd, int k);
 int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, int Cin, int Cout,
                           int kd, int k, dsm_stream_t stream);
 
-/* weights for a launch with dsm_conv3d_args.x_s3 set (same size as dsm_conv_packed_weight_bytes):
- * torch layout (Cout, Cin, [kd,] 3, 3), kd in {1, 3}, Cin % 32 == 0 */
-int dsm_conv_pack_weights_s3in(const void* w_torch, void* w_packed, int Cin, int Cout, int kd,
-                               int k, dsm_stream_t stream);
+/* (ABI v6) max |x| over n floats, folded into *amax (atomic maximum on the float bits; the caller
+ * zeroes it first): the `x_amax` of a tensor no launch of this library produced. */
+int dsm_absmax(const void* x, size_t n, float* amax, dsm_stream_t stream);
 
 int dsm_conv3d_fwd(const dsm_conv3d_args* args, dsm_stream_t stream);
 
@@ -288,9 +306,6 @@ typedef struct dsm_conv3d_s3_args {
    * the first 3-D convolution.  Di = the number of disparity planes. */
   int vol_virtual;
   int vol_mask_left;
-  /* ABI v5.  0 = the library's default; 1 = 8 x 32 output tile, one workgroup per CU; 2 = 4 x 32 tile, two
-   * workgroups per CU.  Same arithmetic and results either way (speed only). */
-  int tiling;
 } dsm_conv3d_s3_args;
 /* split feature maps for a virtual volume: fL, fR (B,C,H,W) NCHW fp32 -> fs,
  * dsm_concat_volume_s3_scratch_bytes(B,C,H,W) bytes. */
@@ -377,15 +392,6 @@ int dsm_warp_abs_error(const void* L, const void* R, const void* disp, void* out
 int dsm_decoder_cat(const void* up, const void* bias, const void* pr, const void* skip, void* out,
                     int B, int Cu, int Cp, int Cs, int Hu, int Wu, int Hp, int Wp, int Hs, int Ws,
                     int relu, dsm_stream_t stream);
-
-/* (ABI v5) PSMNet's first tower layer on the raw images, both views in one launch:
- *   out = relu?( conv2d(img, w; k3, stride 2, pad 1) * scale + shift )   (submodule.py:70-72, 10-13)
- * left, right (B,3,H,W) NCHW fp32 (right = NULL: one view); w_taps [27][32]: the (32,3,3,3) torch
- * weight transposed to tap-major (tap = (c*3 + ky)*3 + kx); scale / shift [32] or NULL;
- * out (2B or B, 32, Ho, Wo) in NHWC memory, Ho = (H-1)/2 + 1.  Exact fp32 FMAs on the VALU. */
-int dsm_conv2d_first3_fwd(const void* left, const void* right, const void* w_taps, const float* scale,
-                          const float* shift, void* out, int B, int H, int W, int relu,
-                          dsm_stream_t stream);
 
 /* (ABI v5) Image staging of the 2-D towers (models/psmnet/stackhourglass.py:118-121 feeds the two
  * views through feature_extraction one after the other; in eval mode they share one batch):

@@ -1,0 +1,73 @@
+"""Per-layer timing of the PSMNet forward's convolution shapes (384x1280, D = 192) in every
+precision mode, in one process: `python scripts/ab_precision.py [--modes bf16x3,f16x2,f16]`.
+HIP events around REP back-to-back launches of one layer (inputs resident, L2-warm weights)."""
+import argparse
+import sys
+sys.path.insert(0, ".")
+import torch
+from dsmnet_amd import costvolume as cv, _lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--modes", default="bf16x3,f16x2,f16")
+ap.add_argument("--rep", type=int, default=30)
+ap.add_argument("--only", default="")
+args = ap.parse_args()
+
+# name, kind, cin, cout, stride, transposed, dil, shape (B, [D,] H, W)
+LAYERS = [
+    ("2d 32->32 192x640 x8", "2d", 32, 32, 1, False, 1, (2, 192, 640)),
+    ("2d 64->64 96x320 x31", "2d", 64, 64, 1, False, 1, (2, 96, 320)),
+    ("2d 128->128 96x320 x7", "2d", 128, 128, 1, False, 1, (2, 96, 320)),
+    ("2d 128->128 dil2 x6", "2d", 128, 128, 1, False, 2, (2, 96, 320)),
+    ("2d 320->128 lastconv", "2d", 320, 128, 1, False, 1, (2, 96, 320)),
+    ("3d 64->32 48x96x320", "3d", 64, 32, 1, False, 1, (1, 48, 96, 320)),
+    ("3d 32->32 48x96x320 x6", "3d", 32, 32, 1, False, 1, (1, 48, 96, 320)),
+    ("3d 32->64 s2 x3", "3d", 32, 64, 2, False, 1, (1, 48, 96, 320)),
+    ("3d 64->64 24x48x160 x3", "3d", 64, 64, 1, False, 1, (1, 24, 48, 160)),
+    ("3d 64->64 s2 x3", "3d", 64, 64, 2, False, 1, (1, 24, 48, 160)),
+    ("3d 64->64 12x24x80 x3", "3d", 64, 64, 1, False, 1, (1, 12, 24, 80)),
+    ("deconv 64->64 12x24x80 x3", "3d", 64, 64, 2, True, 1, (1, 12, 24, 80)),
+    ("deconv 64->32 24x48x160 x3", "3d", 64, 32, 2, True, 1, (1, 24, 48, 160)),
+]
+
+
+def bench(fn, rep):
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(rep):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / rep * 1e3
+
+
+variants = [(m, f, t) for m in args.modes.split(",")
+            for f, t in ((0, ""), (_lib.DSM_CONV_NO_NSPLIT, " nosplit"))]
+print("%-30s" % "layer" + "".join("%16s" % (m + t) for m, f, t in variants))
+for name, kind, cin, cout, stride, tr, dil, shape in LAYERS:
+    if args.only and args.only not in name:
+        continue
+    torch.manual_seed(0)
+    x = torch.randn(shape[0], cin, *shape[1:], device="cuda").relu()
+    if kind == "2d":
+        x = x.contiguous(memory_format=torch.channels_last)
+        w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+        packed = cv.pack_conv2d_weight(w)
+        run = lambda: cv.conv2d_block(x, packed, cout, relu=1, dilation=dil)
+    else:
+        x = x.contiguous(memory_format=torch.channels_last_3d)
+        w = torch.randn(*((cin, cout) if tr else (cout, cin)), 3, 3, 3, device="cuda") * 0.05
+        packed = cv.pack_conv3d_weight(w, tr)
+        run = lambda: cv.conv3d_block(x, packed, cout, stride=stride, transposed=tr, relu=1)
+    row = "%-30s" % name
+    for mode, flags, _ in variants:
+        o1, o2 = cv.set_option("conv_precision", mode), cv.set_option("conv_flags", flags)
+        with cv.amax_scope(x.device):
+            if cv.needs_amax():
+                cv.absmax(x)
+            row += "%16.1f" % bench(run, args.rep)
+        cv.set_option("conv_precision", o1), cv.set_option("conv_flags", o2)
+    print(row, flush=True)

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(raw, name), "missing export: " + name
-    assert hip_lib.dsm_abi_version() == 5
+    assert hip_lib.dsm_abi_version() == 6
     assert hip_lib.dsm_strerror(0) == b"ok"
     assert b"not supported" in hip_lib.dsm_strerror(-2)
 
@@ -55,9 +55,9 @@ def test_argument_validation_returns_codes(hip_lib):
     assert hip_lib.dsm_conv3d_fwd(ctypes.byref(a), null) == -1          # output larger than natural
     a.Do, a.x = 4, 20
     assert hip_lib.dsm_conv3d_fwd(ctypes.byref(a), null) == -4          # misaligned
-    assert hip_lib.dsm_conv3d_packed_weight_bytes(32, 32, 0) == 32 * 32 * 27 * (4 + 6)   # fp32 fragments + 3 bf16 planes
+    assert hip_lib.dsm_conv3d_packed_weight_bytes(32, 32, 0) == 32 * 32 * 27 * (4 + 6 + 4) + 16   # fp32 fragments + 3 bf16 planes + header, 2 fp16 planes
     assert hip_lib.dsm_conv3d_packed_weight_bytes(128, 128, 0) == 128 * 128 * 27 * 4      # no bf16x3 variant
-    assert hip_lib.dsm_conv_packed_weight_bytes(128, 128, 1, 3) == 128 * 128 * 9 * (4 + 6)
+    assert hip_lib.dsm_conv_packed_weight_bytes(128, 128, 1, 3) == 128 * 128 * 9 * (4 + 6 + 4) + 16
     assert hip_lib.dsm_conv_packed_weight_bytes(128, 32, 1, 1) == 128 * 32 * 4
     # ABI v5: weight gradients (flags argument), the 2-D entry point, the S3 kernel's tiling field
     assert hip_lib.dsm_conv3d_wgrad(null, one, one, one, 1, 32, 32, 4, 4, 4, 4, 4, 4, 1, 0, null) == -1
@@ -71,10 +71,22 @@ def test_argument_validation_returns_codes(hip_lib):
     s3.x_s3 = s3.w_packed = s3.y = 16
     s3.B, s3.Cin, s3.Cout = 1, 32, 32
     s3.Di = s3.Hi = s3.Wi = s3.Do = s3.Ho = s3.Wo = 4
-    s3.tiling = 3
-    assert hip_lib.dsm_conv3d_s3_fwd(ctypes.byref(s3), null) == -1        # tilings are 0 (default), 1, 2
-    s3.tiling, s3.Cout = 2, 64
+    s3.Cout = 64
     assert hip_lib.dsm_conv3d_s3_fwd(ctypes.byref(s3), null) == -2        # Cout = 32 only
+    # ABI v6: precision / x_amax of the split kernels, dsm_absmax
+    a.x, a.precision = 16, 7
+    assert hip_lib.dsm_conv3d_fwd(ctypes.byref(a), null) == -1            # unknown precision
+    a.precision = _lib.DSM_PREC_F16X2
+    assert hip_lib.dsm_conv3d_fwd(ctypes.byref(a), null) == -1            # a split kernel without x_amax
+    buf = ctypes.create_string_buffer(96)
+    a.x_amax = 16
+    assert hip_lib.dsm_conv3d_plan(ctypes.byref(a), buf, 96) == 0 and b"f16x2" in buf.value
+    a.precision = _lib.DSM_PREC_F16
+    assert hip_lib.dsm_conv3d_plan(ctypes.byref(a), buf, 96) == 0 and b"_f16_" in buf.value
+    a.precision = _lib.DSM_PREC_F32
+    assert hip_lib.dsm_conv3d_plan(ctypes.byref(a), buf, 96) == 0 and b"bf16x3" in buf.value
+    assert hip_lib.dsm_absmax(null, 4, one, null) == -1
+    assert hip_lib.dsm_absmax(ctypes.c_void_p(20), 4, one, null) == -4
 
 
 def test_ops_refuse_cpu_tensors():

@@ -190,41 +190,6 @@ def test_graphed_forward_equals_eager(hip_lib):
         GraphedForward(m.train(), a, b)
 
 
-def test_psmnet_heads_beside_the_trunk(hip_lib):
-    """``overlap_heads``: classif1 / classif2 and their soft-argmin heads on a second stream beside the
-    next hourglass -- the same kernels on the same data, so the disparities are bit-identical to the
-    serial forward, eagerly (repeated: a stream-ordering bug would show as a changing result) and
-    replayed from a hipGraph that captures both branches."""
-    from dsmnet_amd import costvolume as cv
-    from dsmnet_amd.graphs import GraphedForward
-    from dsmnet_amd.models import model_create_by_name
-    torch.manual_seed(0)
-    m = model_create_by_name("psmnet", 192).cuda().eval()
-    for i in (1, 2, 3):
-        with torch.no_grad():
-            getattr(m, "classif%d" % i)[2].weight.mul_(1e-3)
-    a, b = torch.rand(1, 3, 256, 512, device="cuda"), torch.rand(1, 3, 256, 512, device="cuda")
-    c, d = torch.rand(1, 3, 256, 512, device="cuda"), torch.rand(1, 3, 256, 512, device="cuda")
-    with torch.no_grad():
-        want_ab = [t.clone() for t in m(a, b)[1]]
-        want_cd = [t.clone() for t in m(c, d)[1]]
-    old = cv.set_option("overlap_heads", True)
-    try:
-        with torch.no_grad():
-            for _ in range(3):
-                got_ab = [t.clone() for t in m(a, b)[1]]
-                got_cd = [t.clone() for t in m(c, d)[1]]
-                for w, x in zip(want_ab + want_cd, got_ab + got_cd):
-                    assert torch.equal(w, x)
-        g = GraphedForward(m, a, b)
-        rep_cd = [t.clone() for t in g(c, d)[1]]
-        rep_ab = [t.clone() for t in g(a, b)[1]]
-        for w, x in zip(want_ab + want_cd, rep_ab + rep_cd):
-            assert torch.equal(w, x)
-    finally:
-        cv.set_option("overlap_heads", old)
-
-
 @pytest.mark.parametrize("net,size,tol", [("gcnet", (64, 128), 0.0), ("dispnetcorr", (256, 512), 1e-4),
                                          ("iresnet", (256, 512), 5e-3)])
 def test_graphed_forward_other_models(hip_lib, net, size, tol):

@@ -260,20 +260,3 @@ def test_stage_images_nhwc16(cv, shape, pair):
     assert out.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(out[:, : shape[1]], ref)
     assert float(out[:, shape[1]:].abs().max()) == 0.0 if shape[1] < 16 else True
-
-
-@pytest.mark.parametrize("shape,pair", [((2, 3, 18, 38), True), ((1, 3, 17, 41), False)])
-def test_conv2d_first3(cv, shape, pair):
-    """PSMNet's first tower layer on the raw images (VALU kernel, both views in one launch) ==
-    conv2d(k3, s2, p1) * scale + shift, ReLU, on the concatenated views (fp64 reference; odd sizes:
-    the right / bottom border taps)."""
-    left, right = seeded(61, *shape), (seeded(62, *shape) if pair else None)
-    w = seeded(63, 32, 3, 3, 3, scale=0.3)
-    scale, shift = seeded(64, 32).abs() + 0.5, seeded(65, 32)
-    x = left if right is None else torch.cat([left, right], 0)
-    ref = F.relu(F.conv2d(x.double(), w.double(), None, 2, 1) * scale.double()[None, :, None, None]
-                 + shift.double()[None, :, None, None])
-    out = cv.conv2d_first3(dev(left), None if right is None else dev(right),
-                           dev(w.reshape(32, 27).t().contiguous()), dev(scale), dev(shift), relu=True)
-    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
-    assert maxerr(out, ref.float()) <= 2e-5 * max(1.0, ref.abs().max().item())

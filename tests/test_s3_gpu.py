@@ -79,36 +79,6 @@ def test_conv3d_s3_vs_cpu_fp64(cv, shape, cin, relu, res_shape, grid):
     assert torch.equal(only.buf, ys3.buf)
 
 
-@pytest.mark.parametrize("shape,cin,relu,res_shape,grid,virtual", [
-    ((1, 6, 12, 40), 32, 1, None, 0, False),
-    ((2, 5, 9, 33), 64, 2, (5, 9, 33), 7, False),       # ragged tiles (4-row tiles: 3 + partial), batch 2
-    ((1, 13, 17, 70), 32, 1, (12, 16, 69), 5, False),   # cropped skip
-    ((1, 9, 11, 53), 64, 1, None, 9, True),             # the virtual cost volume as input
-])
-def test_conv3d_s3_second_tiling_is_bit_identical(cv, shape, cin, relu, res_shape, grid, virtual):
-    """dsm_conv3d_s3_args.tiling = 2 (4 x 32 tiles, two workgroups per CU, waves split over couts)
-    computes the same arithmetic in the same order as tiling = 1: identical bits on both outputs."""
-    B, D, H, W = shape
-    w = seeded(22, 32, cin, 3, 3, 3, scale=(2.0 / (27 * cin)) ** 0.5).cuda()
-    scale, shift = (seeded(23, 32).abs() + 0.5).cuda(), seeded(24, 32).cuda()
-    res = seeded(25, B, 32, *res_shape).cuda() if res_shape else None
-    if virtual:
-        fL, fR = seeded(41, B, cin // 2, H, W).cuda(), seeded(42, B, cin // 2, H, W).cuda()
-        xs = cv.concat_volume_s3(fL, fR, D, True, materialise=False)
-    else:
-        xs = cv.s3_from_tensor(seeded(21, B, cin, D, H, W).cuda())
-    packed = cv.pack_conv3d_s3_weight(w)
-    got = {}
-    for tiling in (1, 2):
-        old = cv.set_option("s3_tiling", tiling)
-        try:
-            got[tiling] = cv.conv3d_s3_block(xs, packed, scale, shift, res, relu=relu, out="both", grid=grid)
-        finally:
-            cv.set_option("s3_tiling", old)
-    assert torch.equal(got[1][0], got[2][0])
-    assert torch.equal(got[1][1].buf, got[2][1].buf)
-
-
 def test_conv3d_s3_agrees_with_the_fp32_input_mfma_kernel(cv):
     """Same layer on the exact-fp32 MFMA kernel (conv3d.hip) and on the z-sliding bf16x3 kernel."""
     x = seeded(31, 1, 32, 7, 19, 45)
@@ -160,9 +130,9 @@ def test_bf16x3_kernels_write_the_same_result_as_s3(cv, cin, cout, stride, trans
 
 
 def test_psmnet_paths_agree(cv, golden_e2e):
-    """PSMNet eval forward four ways -- default (virtual volume + z-sliding S3 layers), S3 layers on
-    a materialised fp32 volume, S3 hand-over everywhere (towers and hourglasses too: the ``s3in``
-    option), and the r01 path (no S3 at all): each within 1e-3 px of the reference golden."""
+    """PSMNet eval forward (bf16x3) three ways -- virtual volume + z-sliding S3 layers, S3 layers on a
+    materialised fp32 volume, and the r01 path (no S3 at all): each within 1e-3 px of the reference
+    golden."""
     from tests.golden.make_goldens import images
     from tests.helpers import golden_state
     from dsmnet_amd.models import model_create_by_name
@@ -172,70 +142,14 @@ def test_psmnet_paths_agree(cv, golden_e2e):
     m.load_state_dict(sd, strict=True)
     m = m.cuda().eval()
     outs = {}
-    for name, s3, fuse, s3in in (("default", True, True, False), ("s3-on-fp32-volume", True, False, False),
-                                 ("s3-everywhere", True, True, True), ("r01", False, False, False)):
-        o1, o2, o3 = cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse), cv.set_option("s3in", s3in)
+    for name, s3, fuse in (("default", True, True), ("s3-on-fp32-volume", True, False), ("r01", False, False)):
+        o0 = cv.set_option("conv_precision", "bf16x3")
+        o1, o2 = cv.set_option("s3", s3), cv.set_option("fuse_volume", fuse)
         try:
             with torch.no_grad():
                 outs[name] = m(imL.cuda(), imR.cuda())[1]
         finally:
-            cv.set_option("s3", o1), cv.set_option("fuse_volume", o2), cv.set_option("s3in", o3)
+            cv.set_option("s3", o1), cv.set_option("fuse_volume", o2), cv.set_option("conv_precision", o0)
         for pname, p in zip(("pred3", "pred2", "pred1"), outs[name]):
             golden_e2e.compare("e2e.psmnet." + pname, p, 1e-3)
     assert maxerr(outs["default"][0], outs["r01"][0]) <= 1e-3
-
-
-@pytest.mark.parametrize("cin,cout,stride,shape", [
-    (32, 64, 2, (1, 6, 12, 40)), (64, 64, 2, (1, 5, 9, 37)), (64, 64, 1, (2, 3, 7, 35)),
-    (32, 32, 1, (1, 5, 17, 33)), (64, 32, 1, (1, 4, 16, 64)),
-])
-def test_conv3d_bf16x3_reads_s3_input(cv, cin, cout, stride, shape):
-    """The bf16x3 convolution with its input handed over pre-split (x_s3): equal to the same layer
-    fed the fp32 tensor up to summation order, and to the CPU reference."""
-    B, D, H, W = shape
-    x = seeded(61, B, cin, D, H, W)
-    w = seeded(62, cout, cin, 3, 3, 3, scale=0.05)
-    sc, sh = seeded(63, cout).abs() + 0.5, seeded(64, cout)
-    want = F.conv3d(x.double(), w.double(), stride=stride, padding=1)
-    want = (want * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1)).relu().float()
-    assert cv.conv_s3in_eligible(cin, cout, stride, False)
-    xs = cv.s3_from_tensor(x.cuda())
-    y, ys3 = cv.conv3d_block(xs, cv.pack_conv_weight_s3in(w.cuda()), cout, sc.cuda(), sh.cuda(),
-                             stride=stride, relu=1, out="both")
-    ref = cv.conv3d_block(x.cuda(), cv.pack_conv3d_weight(w.cuda(), False), cout, sc.cuda(), sh.cuda(),
-                          stride=stride, relu=1)
-    tol = 2e-5 * max(1.0, want.abs().max().item())
-    assert maxerr(y, want) <= tol and maxerr(y, ref) <= tol
-    assert torch.equal(ys3.to_tensor(), y)
-
-
-@pytest.mark.parametrize("cin,cout,dil,hw,res", [
-    (32, 32, 1, (192, 96), True),      # 16-row tiles
-    (32, 32, 1, (20, 45), False),      # 8-row tiles, ragged
-    (64, 64, 1, (33, 70), True),
-    (64, 128, 1, (24, 40), False),
-    (128, 128, 1, (17, 33), True),
-    (128, 128, 2, (24, 50), True),     # dilation 2 (layer4)
-])
-def test_conv2d_bf16x3_reads_s3_input(cv, cin, cout, dil, hw, res):
-    """2-D tower layers (models/psmnet/submodule.py:10-43) with the S3 hand-over between them."""
-    H, W = hw
-    x = seeded(71, 2, cin, H, W)
-    w = seeded(72, cout, cin, 3, 3, scale=0.05)
-    sc, sh = seeded(73, cout).abs() + 0.5, seeded(74, cout)
-    r = seeded(75, 2, cout, H, W) if res else None
-    want = F.conv2d(x.double(), w.double(), padding=dil, dilation=dil)
-    want = want * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
-    if res:
-        want = want + r.double()
-    want = want.float()
-    assert cv.conv_s3in_eligible(cin, cout, 1, False, kd=1, k=3, dil=dil)
-    xs = cv.s3_from_tensor(x.cuda().unsqueeze(2))                      # the map as a (B,C,1,H,W) volume
-    y, ys3 = cv.conv2d_block(xs, cv.pack_conv_weight_s3in(w.cuda()), cout, sc.cuda(), sh.cuda(),
-                             None if r is None else r.cuda(), dilation=dil, out="both")
-    assert tuple(y.shape) == (2, cout, H, W)
-    assert maxerr(y, want) <= 2e-5 * max(1.0, want.abs().max().item())
-    assert torch.equal(ys3.to_tensor().squeeze(2), y)
-    ref = cv.conv2d_block(x.cuda(), cv.pack_conv2d_weight(w.cuda()), cout, sc.cuda(), sh.cuda(),
-                          None if r is None else r.cuda(), dilation=dil)
-    assert maxerr(y, ref) <= 2e-5 * max(1.0, want.abs().max().item())
