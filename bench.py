@@ -346,10 +346,10 @@ def main():
             # The cost-volume build (the north-star's >= 60 %-of-HBM kernel).  The default forward
             # never materialises the volume (dres0's first convolution stages it from the split
             # feature maps), so the build is measured (1) inside the forward that DOES materialise it
-            # -- the same model with the r01 path selected (costvolume option "s3" off), per-launch
+            # -- the same model with the volume materialised (costvolume option "fuse_volume" off), per-launch
             # HIP events as above -- and (2) launched back to back, where every launch must first
             # drain the previous one's dirty Infinity-Cache lines.
-            old_s3 = costvolume.set_option("s3", False)
+            old_s3 = costvolume.set_option("fuse_volume", False)
             try:
                 for _ in range(2):
                     model(left, right)
@@ -366,7 +366,7 @@ def main():
                 volume_seq_us = ve["ms"] / ve["launches"] * 1e3 if ve else None
             finally:
                 costvolume.set_timer(None)
-                costvolume.set_option("s3", old_s3)
+                costvolume.set_option("fuse_volume", old_s3)
             fl, fr = model.features(left, right)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             costvolume.concat_volume(fl, fr, MAXDISP // 4, True)
@@ -400,10 +400,11 @@ def main():
                        "launch": launch,
                        "launcher": ("self-launched child ranks" if os.environ.get("DSM_BENCH_SELF_LAUNCHED")
                                     else ("external launcher" if world > 1 else "single process")),
-                       "conv_precision": ("fp32-input MFMA" if costvolume.get_option("conv_fp32") else "bf16x3") +
-                                         " (DSM_CONV_PRECISION=fp32, read by the host module, keeps the fp32-input MFMA)",
-                       "trunk_path": "z-sliding S3 kernel for the 32-channel stride-1 layers, cost volume "
-                                     "never materialised" if costvolume.get_option("s3") else "r01 kernels"},
+                       "conv_precision": costvolume.get_option("conv_precision") +
+                                         " (costvolume option conv_precision / DSM_CONV_PRECISION: f16x2 | bf16x3 | fp32 are "
+                                         "fp32-accurate, f16 is the reduced-precision mode)",
+                       "trunk_path": "z-sliding kernel for the 32-channel stride-1 layers, cost volume "
+                                     "never materialised"},
             # rank 0's per-step GPU time from one HIP event per step inside the timed region
             "step_ms": {"median": round(statistics.median(step_ms), 3), "min": round(min(step_ms), 3),
                         "max": round(max(step_ms), 3), "mean_wall": round(ms_per_step, 3)},
@@ -448,11 +449,18 @@ def main():
             result["parity_max_abs_px_vs_cpu"] = err
         result["precision"] = {
             "storage_and_accumulate": "f32",
-            "conv_products": ("fp32-input MFMA" if costvolume.get_option("conv_fp32") else
-                              "each fp32 operand split exactly into 3 bf16 terms; 6 bf16 MFMAs per product, "
-                              "dropped terms <= 3*2^-25 relative; fp32 accumulate"),
-            "conv_error_vs_float64": "max rel 0.8-1.3e-6, rms 4.1-5.9e-7 on 6 layer shapes; the fp32-input MFMA "
-                                     "kernels measure 0.8-1.5e-6 / 4.2-5.9e-7 (scripts/precision_check.py, DESIGN.md 3.2a)",
+            "conv_products": {
+                "fp32": "fp32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products and sums",
+                "bf16x3": "each fp32 operand split exactly into 3 bf16 terms; 6 bf16 MFMAs per product, "
+                          "dropped terms <= 3*2^-25 relative; fp32 accumulate",
+                "f16x2": "each fp32 operand scaled by a power of two (from the tensor's device-side absolute "
+                         "maximum) and split into 2 fp16 terms (22 significand bits); 3 fp16 MFMAs per product; "
+                         "fp32 accumulate",
+                "f16": "operands rounded to fp16 after the power-of-two scaling; 1 MFMA per product; fp32 "
+                       "accumulate (reduced precision: BASELINE config #5)"}[costvolume.get_option("conv_precision")],
+            "conv_error_vs_float64": "max rel / rms on 8 layer shapes, inputs 1e-9 .. 1e7 (scripts/precision_check.py, "
+                                     "profiles/r03_precision.md): fp32-input MFMA 0.8-1.5e-6 / 4.2-5.9e-7, bf16x3 "
+                                     "0.8-1.5e-6 / 4.1-5.9e-7, f16x2 0.6-1.1e-6 / 3.2-4.4e-7, f16 3e-4 / 2.9e-4",
             "gate": "forward disparity vs the fp32 CPU reference path <= 1e-3 px (parity_max_abs_px_vs_cpu)"}
         print(json.dumps(result), flush=True)
     if dist is not None:

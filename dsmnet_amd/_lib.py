@@ -30,17 +30,6 @@ class Bn3dArgs(ctypes.Structure):
                 ("relu", c_int), ("momentum", ctypes.c_float), ("eps", ctypes.c_float)]
 
 
-class Conv3dS3Args(ctypes.Structure):
-    """struct dsm_conv3d_s3_args (include/dsmnet_hip.h)."""
-    _fields_ = [("x_s3", c_void_p), ("w_packed", c_void_p), ("scale", c_void_p),
-                ("shift", c_void_p), ("residual", c_void_p), ("y", c_void_p), ("y_s3", c_void_p),
-                ("B", c_int), ("Cin", c_int), ("Cout", c_int),
-                ("Di", c_int), ("Hi", c_int), ("Wi", c_int),
-                ("Do", c_int), ("Ho", c_int), ("Wo", c_int),
-                ("Dr", c_int), ("Hr", c_int), ("Wr", c_int),
-                ("relu", c_int), ("grid", c_int), ("vol_virtual", c_int), ("vol_mask_left", c_int)]
-
-
 class Conv3dArgs(ctypes.Structure):
     """struct dsm_conv3d_args (include/dsmnet_hip.h)."""
     _fields_ = [("x", c_void_p), ("w_packed", c_void_p), ("scale", c_void_p),
@@ -50,8 +39,9 @@ class Conv3dArgs(ctypes.Structure):
                 ("Do", c_int), ("Ho", c_int), ("Wo", c_int),
                 ("Dr", c_int), ("Hr", c_int), ("Wr", c_int),
                 ("stride", c_int), ("transposed", c_int), ("relu", c_int),
-                ("kd", c_int), ("k", c_int), ("dil", c_int), ("y_s3", c_void_p),
-                ("flags", c_int), ("precision", c_int), ("x_amax", c_void_p), ("y_amax", c_void_p)]
+                ("kd", c_int), ("k", c_int), ("dil", c_int),
+                ("flags", c_int), ("precision", c_int), ("x_amax", c_void_p), ("y_amax", c_void_p),
+                ("vol_virtual", c_int), ("vol_mask_left", c_int)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in dsmnet_hip.h
@@ -74,15 +64,6 @@ SIGNATURES = {
     "dsm_conv2d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
     "dsm_conv3d_cout1_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "dsm_deconv3d_cout1_bwd": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
-    "dsm_s3_bytes": (c_size_t, [c_int] * 5),
-    "dsm_s3_from_ndhwc": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
-    "dsm_s3_to_ndhwc": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
-    "dsm_concat_volume_s3_scratch_bytes": (c_size_t, [c_int] * 4),
-    "dsm_concat_volume_s3_fwd": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
-    "dsm_features_s3": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
-    "dsm_conv3d_s3_packed_weight_bytes": (c_size_t, [c_int] * 2),
-    "dsm_conv3d_s3_pack_weights": (c_int, [c_void_p] * 2 + [c_int] * 2 + [c_void_p]),
-    "dsm_conv3d_s3_fwd": (c_int, [ctypes.POINTER(Conv3dS3Args), c_void_p]),
     "dsm_bn3d_train_fwd": (c_int, [ctypes.POINTER(Bn3dArgs), c_void_p]),
     "dsm_bn3d_train_bwd": (c_int, [ctypes.POINTER(Bn3dArgs), c_void_p]),
     "dsm_decoder_cat": (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p]),

@@ -43,7 +43,6 @@ class _Folded(object):
     def __init__(self):
         self.key = None
         self.packed = self.scale = self.shift = None
-        self.packed_s3 = None            # packing for the z-sliding S3 kernel, made on first use
 
     def get(self, conv, bn):
         transposed = isinstance(conv, nn.ConvTranspose3d)
@@ -70,16 +69,7 @@ class _Folded(object):
                 else:
                     self.scale = self.shift = None
             self.key = key
-            self.packed_s3 = None
         return self.packed, self.scale, self.shift
-
-    def get_s3(self, conv, bn):
-        """(weights packed for ``conv3d_s3_block``, scale, shift)."""
-        _, scale, shift = self.get(conv, bn)
-        if self.packed_s3 is None:
-            with torch.no_grad():
-                self.packed_s3 = cv.pack_conv3d_s3_weight(conv.weight)
-        return self.packed_s3, scale, shift
 
 
 def _check_conv(conv):
@@ -133,33 +123,19 @@ def _run_block_batch_stats(folded, conv, bn, x, residual, relu):
     return y
 
 
-def _s3_layer(conv):
-    """Does this layer run on the z-sliding S3 kernel (given an S3 input)?"""
-    return (cv.get_option("s3") and cv.get_option_bf16x3() and isinstance(conv, nn.Conv3d) and
-            cv.conv3d_s3_eligible(conv.in_channels, conv.out_channels, conv.stride[0], False))
-
-
-def takes_s3(conv):
-    """An S3 input is worth making for this layer."""
-    return _s3_layer(conv)
-
-
 def _fast_eval(conv, bn, x):
     """Eval-mode, no autograd: the fused single-launch kernels apply."""
     if bn is not None and bn.training:
         return False
-    if isinstance(x, cv.S3Volume):
+    if isinstance(x, cv.VirtualVolume):
         return True
     return not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad))
 
 
-def run_block(folded, conv, bn, x, residual=None, relu=RELU_NONE, out="f32"):
+def run_block(folded, conv, bn, x, residual=None, relu=RELU_NONE):
     """conv (+ BN) (+ cropped skip) (+ ReLU); one launch in eval mode.  ``x``: a tensor or (eval
-    only) an ``S3Volume``; ``out``: "f32" | "s3" | "both" (eval only: the S3 forms exist for the
-    kernels' benefit, autograd never sees them)."""
+    only) a ``costvolume.VirtualVolume``."""
     if not _fast_eval(conv, bn, x):
-        if out != "f32":
-            raise ValueError("S3 outputs exist on the eval path only")
         if bn is not None and bn.training:
             return _run_block_batch_stats(folded, conv, bn, x, residual, relu)
         # autograd through a block without train-mode BN (bare convolutions such as classif*.2,
@@ -176,21 +152,10 @@ def run_block(folded, conv, bn, x, residual=None, relu=RELU_NONE, out="f32"):
         if relu == RELU_AFTER_ADD:
             y = torch.relu(y)
         return y
-    transposed = isinstance(conv, nn.ConvTranspose3d)
-    if isinstance(x, cv.S3Volume):
-        if _s3_layer(conv):
-            packed, scale, shift = folded.get_s3(conv, bn)
-            return cv.conv3d_s3_block(x, packed, scale, shift, residual, relu=relu, out=out)
-        x = x.to_tensor()                      # a consumer without an S3 path (not a reference pattern)
     packed, scale, shift = folded.get(conv, bn)
-    if out != "f32" and not cv.conv3d_supports_s3_out(conv.in_channels, conv.out_channels,
-                                                      conv.stride[0], transposed):
-        y = cv.conv3d_block(x, packed, conv.out_channels, scale, shift, residual,
-                            stride=conv.stride[0], transposed=transposed, relu=relu)
-        ys3 = cv.s3_from_tensor(y)
-        return ys3 if out == "s3" else (y, ys3)
     return cv.conv3d_block(x, packed, conv.out_channels, scale, shift, residual,
-                           stride=conv.stride[0], transposed=transposed, relu=relu, out=out)
+                           stride=conv.stride[0], transposed=isinstance(conv, nn.ConvTranspose3d),
+                           relu=relu)
 
 
 class ConvBN3d(nn.Sequential):
@@ -213,7 +178,7 @@ class ConvBN3d(nn.Sequential):
         self._has_act = act is not None
         self._folded = _Folded()
 
-    def forward(self, x, residual=None, relu=False, out="f32"):
+    def forward(self, x, residual=None, relu=False):
         conv = self[0]
         bn = self[self._bn_idx] if self._bn_idx is not None else None
         if self._has_act:
@@ -222,10 +187,7 @@ class ConvBN3d(nn.Sequential):
             mode = RELU_BEFORE_ADD
         else:
             mode = RELU_AFTER_ADD if relu else RELU_NONE
-        return run_block(self._folded, conv, bn, x, residual, mode, out)
-
-    def eats_s3(self):
-        return takes_s3(self[0])
+        return run_block(self._folded, conv, bn, x, residual, mode)
 
 
 class Chain3d(nn.Sequential):
@@ -238,10 +200,7 @@ class Chain3d(nn.Sequential):
         super(Chain3d, self).__init__(*layers)
         self._plain = {}
 
-    def forward(self, x, residual=None, relu=False, out="f32"):
-        """``out`` is the format of the chain's result ("f32" | "s3" | "both"); between two layers
-        the activation travels as S3 only when the next convolution runs on the S3 kernel
-        (eval mode, no autograd), otherwise as an fp32 tensor."""
+    def forward(self, x, residual=None, relu=False):
         mods = list(self)
         convs = [i for i, m in enumerate(mods) if isinstance(m, (ConvBN3d, nn.Conv3d, nn.ConvTranspose3d))]
         last_conv = convs[-1]
@@ -251,37 +210,20 @@ class Chain3d(nn.Sequential):
             nxt_relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
             res = residual if i == last_conv else None
             want_relu = nxt_relu or (relu and i == last_conv)
-            if i == last_conv:
-                fmt = out
-            else:
-                nxt = mods[convs[convs.index(i) + 1]]
-                nconv = nxt[0] if isinstance(nxt, ConvBN3d) else nxt
-                fmt = "s3" if (takes_s3(nconv) and self._eval_no_grad(m, x)) else "f32"
             if isinstance(m, ConvBN3d):
                 if res is not None and nxt_relu:
                     raise ValueError("skip-add before an inner ReLU is not a reference pattern")
-                x = m(x, residual=res, relu=want_relu, out=fmt)
+                x = m(x, residual=res, relu=want_relu)
             elif isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)):
                 _check_conv(m)
                 folded = self._plain.setdefault(i, _Folded())
-                x = run_block(folded, m, None, x, res,
-                              RELU_AFTER_ADD if want_relu else RELU_NONE, fmt)
+                x = run_block(folded, m, None, x, res, RELU_AFTER_ADD if want_relu else RELU_NONE)
             elif isinstance(m, nn.ReLU):
                 raise ValueError("ReLU without a preceding convolution in a 3-D chain")
             else:
                 raise TypeError("unsupported layer in a 3-D chain: %r" % (m,))
             i += 2 if nxt_relu else 1
         return x
-
-    @staticmethod
-    def _eval_no_grad(m, x):
-        conv = m[0] if isinstance(m, ConvBN3d) else m
-        bn = m[m._bn_idx] if isinstance(m, ConvBN3d) and m._bn_idx is not None else None
-        return _fast_eval(conv, bn, x)
-
-    def eats_s3(self):
-        m = next(m for m in self if isinstance(m, (ConvBN3d, nn.Conv3d, nn.ConvTranspose3d)))
-        return takes_s3(m[0] if isinstance(m, ConvBN3d) else m)
 
 
 class Conv3dHip(nn.Conv3d):

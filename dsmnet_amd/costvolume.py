@@ -328,18 +328,26 @@ def conv3d_out_size(in_size, stride, transposed):
 
 
 def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, stride=1,
-                 transposed=False, relu=False, out_size=None, out="f32"):
+                 transposed=False, relu=False, out_size=None):
     """y = relu?(conv(x) * scale + shift (+ residual, cropped to the common size)).
 
     ``x`` is (B,Cin,D,H,W); it is consumed in NDHWC memory (converted if needed) and
     the result is returned as a channels_last_3d tensor.  With ``residual`` the output
     takes the element-wise minimum of the two spatial sizes -- ``myadd_3d`` semantics
-    (stackhourglass.py:10-20).  ``out``: "f32" -> tensor; "s3" / "both" -> the result (also) as an
-    S3Volume for a following ``conv3d_s3_block`` (bf16x3 kernels only).  Inference only.
-    What the MFMA kernels multiply in follows the ``conv_precision`` option (``set_option``)."""
-    _require_device("conv3d_block", x, scale, shift, residual)
-    x = to_channels_last_3d(x)
-    B, cin, Di, Hi, Wi = x.shape
+    (stackhourglass.py:10-20).  ``x`` may be a ``VirtualVolume`` (Conv3d k3 s1 to 32 channels: the
+    z-sliding kernel stages the never-materialised cost volume from the towers' output).
+    Inference only.  What the MFMA kernels multiply in follows the ``conv_precision`` option."""
+    virtual = x if isinstance(x, VirtualVolume) else None
+    if virtual is not None:
+        x = virtual.features                     # NHWC (2B, C, H, W): staged as the volume's planes
+        if stride != 1 or transposed or cout != 32:
+            raise ValueError("a virtual cost volume feeds a Conv3d(k3, s1) to 32 channels only")
+        _require_device("conv3d_block", x, scale, shift, residual)
+        B, cin, Di, Hi, Wi = virtual.shape
+    else:
+        _require_device("conv3d_block", x, scale, shift, residual)
+        x = carry_amax(to_channels_last_3d(x), x)
+        B, cin, Di, Hi, Wi = x.shape
     Do, Ho, Wo = conv3d_out_size((Di, Hi, Wi), stride, transposed)
     a = _lib.Conv3dArgs()
     if residual is not None:
@@ -351,16 +359,10 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
         Do, Ho, Wo = min(Do, a.Dr), min(Ho, a.Hr), min(Wo, a.Wr)
     if out_size is not None:                     # a corner of the natural output (bwd-data crops)
         Do, Ho, Wo = (min(n, int(o)) for n, o in zip((Do, Ho, Wo), out_size))
-    oshape = (B, cout, Do, Ho, Wo)
-    y = ys3 = None
-    if out in ("f32", "both"):
-        y = torch.empty(oshape, device=x.device, dtype=torch.float32, memory_format=_CL3D)
-    if out in ("s3", "both"):
-        ys3 = S3Volume(_s3_alloc(oshape, x.device), oshape)
+    y = torch.empty((B, cout, Do, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL3D)
     a.x = x.data_ptr()
     a.w_packed = packed_weight.data_ptr()
-    a.y = None if y is None else y.data_ptr()
-    a.y_s3 = None if ys3 is None else ys3.buf.data_ptr()
+    a.y = y.data_ptr()
     a.scale = None if scale is None else scale.data_ptr()
     a.shift = None if shift is None else shift.data_ptr()
     a.residual = None if residual is None else residual.data_ptr()
@@ -369,6 +371,8 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
     a.Do, a.Ho, a.Wo = Do, Ho, Wo
     a.stride, a.transposed, a.relu = int(stride), int(transposed), int(relu)
     a.flags = _conv_flags()
+    if virtual is not None:
+        a.vol_virtual, a.vol_mask_left = 1, int(virtual.mask_left)
     keep = _set_precision(a, x, y if cout > 1 else None)
     # FLOPs as SURVEY.md section 8d counts them: 2*27*Cin*Cout per output voxel (conv) or
     # per input voxel (transposed conv)
@@ -379,25 +383,7 @@ def conv3d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
         rc = _lib.load().dsm_conv3d_fwd(ctypes.byref(a), _stream())
     _lib.check(rc, "dsm_conv3d_fwd")
     del keep
-    if out == "f32":
-        return y
-    if out == "s3":
-        return ys3
-    return y, ys3
-
-
-def conv3d_supports_s3_out(cin, cout, stride, transposed):
-    """Layers whose kernel has the S3 epilogue: the bf16x3 3-D kernels (conv3d.hip make_plan)."""
-    if cout not in (32, 64):
-        return False
-    if transposed:
-        return cin % 32 == 0
-    return cin % 16 == 0 and get_option_bf16x3()
-
-
-def get_option_bf16x3():
-    """The split kernels run in their bf16x3 form (the only one with the S3 hand-over format)."""
-    return _OPTIONS["conv_precision"] == "bf16x3"
+    return y
 
 
 def conv3d_plan_name(args):
@@ -408,8 +394,7 @@ def conv3d_plan_name(args):
 
 
 # ----------------------------------------------------------------------------
-# S3 activations (fp32 stored pre-split for the bf16 matrix pipe) and the z-sliding convolution
-# that consumes them -- csrc/conv_s3.hip, include/dsmnet_hip.h "S3"
+# host-side options, absolute maxima of the fp16 precisions, the virtual cost volume
 # ----------------------------------------------------------------------------
 import os as _os
 
@@ -422,10 +407,10 @@ def _env_precision():
     v = _os.environ.get("DSM_CONV_PRECISION", "")
     if v and v not in _PRECISIONS:
         raise ValueError("DSM_CONV_PRECISION must be one of %s, got %r" % (_PRECISIONS, v))
-    return v or "bf16x3"
+    return v or "f16x2"
 
 
-_OPTIONS = {"s3": True, "fuse_volume": True, "conv_precision": _env_precision(), "conv_flags": 0}
+_OPTIONS = {"fuse_volume": True, "conv_precision": _env_precision(), "conv_flags": 0}
 
 
 def set_option(name, value):
@@ -437,7 +422,6 @@ def set_option(name, value):
                   BASELINE config #5 (forward, backward-data and weight gradients);
         "fp32"    the exact fp32-input MFMA (v_mfma_f32_32x32x2_f32);
     ``conv_fp32`` -- older spelling: True = "fp32", False = "bf16x3";
-    ``s3`` -- bf16x3 only: eval-mode 32-channel stride-1 3-D layers run on the z-sliding S3 kernel;
     ``fuse_volume`` -- PSMNet's / GCNet's eval forward never materialises the cost volume: the first
     3-D convolution stages it from the feature maps;
     ``conv_flags`` -- raw dsm_conv3d_args.flags bits (tile height, grid size)."""
@@ -592,145 +576,33 @@ def _set_precision(a, x, y):
     return xa, ya
 
 
-class S3Volume(object):
-    """A (B,C,D,H,W) fp32 activation held in the S3 format: ``buf`` is the raw byte buffer
-    (6 bytes per value), ``shape`` the logical shape.  ``to_tensor()`` returns the fp32 tensor
-    (channels_last_3d) it encodes, bit for bit."""
-    __slots__ = ("buf", "shape", "features")
+class VirtualVolume(object):
+    """A concatenation cost volume that is never written (models/psmnet/stackhourglass.py:124-133,
+    models/gcnet.py:130-135): ``features`` is the towers' output for both views as ONE NHWC tensor
+    (2B, C, H, W) [left maps, then right maps]; the first 3-D convolution (``conv3d_block``; the
+    z-sliding kernel, csrc/conv_zs.hpp) stages plane d as [left | right shifted by d] with x < d
+    zeroed.  ``shape``: the logical (B, 2C, D, H, W).  Inference only."""
+    __slots__ = ("features", "shape", "mask_left")
 
-    def __init__(self, buf, shape, features=None):
-        self.buf, self.shape = buf, tuple(int(v) for v in shape)
-        self.features = features          # (fs, D, mask_left): a cost volume NOT materialised
+    def __init__(self, features, D, mask_left):
+        if features.dim() != 4 or features.shape[0] % 2:
+            raise ValueError("VirtualVolume: features must be (2B, C, H, W), left maps then right maps")
+        if not features.is_contiguous(memory_format=torch.channels_last):
+            features = carry_amax(features.contiguous(memory_format=torch.channels_last), features)
+        self.features = features
+        B2, C, H, W = features.shape
+        self.shape = (B2 // 2, 2 * C, int(D), H, W)
+        self.mask_left = bool(mask_left)
 
     @property
     def device(self):
-        return self.buf.device
-
-    def to_tensor(self):
-        if self.features is not None:
-            raise RuntimeError("this S3Volume is a virtual cost volume (never materialised)")
-        B, C, D, H, W = self.shape
-        out = torch.empty(self.shape, device=self.buf.device, dtype=torch.float32, memory_format=_CL3D)
-        with torch.cuda.device(self.buf.device):
-            rc = _lib.load().dsm_s3_to_ndhwc(_p(self.buf), _p(out), B, C, D, H, W, _stream())
-        _lib.check(rc, "dsm_s3_to_ndhwc")
-        return out
+        return self.features.device
 
 
-def _s3_alloc(shape, device):
-    B, C, D, H, W = shape
-    n = _lib.load().dsm_s3_bytes(B, C, D, H, W)
-    if n == 0:
-        raise ValueError("S3 needs C %% 32 == 0, got shape %s" % (tuple(shape),))
-    return torch.empty(n, device=device, dtype=torch.uint8)
-
-
-def s3_from_tensor(x):
-    """(B,C,D,H,W) fp32 -> S3Volume (lossless)."""
-    _require_device("s3_from_tensor", x)
-    x = to_channels_last_3d(x)
-    B, C, D, H, W = x.shape
-    buf = _s3_alloc(x.shape, x.device)
-    with torch.cuda.device(x.device):
-        rc = _lib.load().dsm_s3_from_ndhwc(_p(x), _p(buf), B, C, D, H, W, _stream())
-    _lib.check(rc, "dsm_s3_from_ndhwc")
-    return S3Volume(buf, x.shape)
-
-
-def concat_volume_s3(fL, fR, D, mask_left, materialise=True):
-    """The concatenation cost volume as an S3Volume (inference only).  ``materialise=False``:
-    only the split feature maps are made (a few MB) and the volume stays virtual -- the
-    z-sliding convolution stages plane d, row y straight from them (shift by d, mask x < d)."""
-    _require_device("concat_volume_s3", fL, fR)
-    _same_shape("concat_volume_s3", fL, fR)
-    fL, fR = fL.contiguous(), fR.contiguous()
-    B, C, H, W = fL.shape
-    lib = _lib.load()
-    nscr = lib.dsm_concat_volume_s3_scratch_bytes(B, C, H, W)
-    if nscr == 0:
-        raise ValueError("concat_volume_s3 needs C %% 32 == 0, got C = %d" % C)
-    fs = torch.empty(nscr, device=fL.device, dtype=torch.uint8)
-    shape = (B, 2 * C, int(D), H, W)
-    if not materialise:
-        with torch.cuda.device(fL.device), _timed("feat_s3_kernel", 4.0 * 2 * B * C * H * W + nscr):
-            rc = lib.dsm_features_s3(_p(fL), _p(fR), _p(fs), B, C, H, W, _stream())
-        _lib.check(rc, "dsm_features_s3")
-        return S3Volume(fs, shape, features=(int(D), int(bool(mask_left))))
-    vol = _s3_alloc(shape, fL.device)
-    # algorithmic bytes as SURVEY.md 8d counts the volume build (fp32): features read + volume written
-    with torch.cuda.device(fL.device), _timed("volume_s3_fwd_kernel", 4.0 * (2 * B * C * H * W + 2 * B * C * D * H * W)):
-        rc = lib.dsm_concat_volume_s3_fwd(_p(fL), _p(fR), _p(fs), _p(vol), B, C, H, W, int(D),
-                                          int(bool(mask_left)), _stream())
-    _lib.check(rc, "dsm_concat_volume_s3_fwd")
-    return S3Volume(vol, shape)
-
-
-def conv3d_s3_eligible(cin, cout, stride, transposed):
-    """Layers the z-sliding S3 kernel implements: Conv3d k3 s1 p1, Cin % 32 == 0 -> Cout = 32."""
-    return (not transposed) and stride == 1 and cout == 32 and cin % 32 == 0
-
-
-def pack_conv3d_s3_weight(weight):
-    _require_device("pack_conv3d_s3_weight", weight)
-    cout, cin = weight.shape[0], weight.shape[1]
-    lib = _lib.load()
-    n = lib.dsm_conv3d_s3_packed_weight_bytes(cin, cout)
-    if n == 0 or tuple(weight.shape[2:]) != (3, 3, 3):
-        raise ValueError("pack_conv3d_s3_weight: unsupported weight shape %s" % (tuple(weight.shape),))
-    w = weight.detach().contiguous()
-    packed = torch.empty(n, device=w.device, dtype=torch.uint8)
-    with torch.cuda.device(w.device):
-        rc = lib.dsm_conv3d_s3_pack_weights(_p(w), _p(packed), cin, cout, _stream())
-    _lib.check(rc, "dsm_conv3d_s3_pack_weights")
-    return packed
-
-
-def conv3d_s3_block(x, packed_weight, scale=None, shift=None, residual=None, relu=0, out="f32",
-                    grid=0):
-    """y = relu?(conv3d_k3s1p1(x) * scale + shift (+ residual, cropped)) with ``x`` an S3Volume and
-    32 output channels.  ``out``: "f32" -> tensor, "s3" -> S3Volume, "both" -> (tensor, S3Volume).
-    Inference only."""
-    if not isinstance(x, S3Volume):
-        raise TypeError("conv3d_s3_block takes an S3Volume")
-    _require_device("conv3d_s3_block", scale, shift, residual)
-    B, cin, Di, Hi, Wi = x.shape
-    Do, Ho, Wo = Di, Hi, Wi
-    a = _lib.Conv3dS3Args()
-    if residual is not None:
-        if residual.shape[0] != B or residual.shape[1] != 32:
-            raise ValueError("conv3d_s3_block: residual has shape %s" % (tuple(residual.shape),))
-        residual = to_channels_last_3d(residual)
-        a.Dr, a.Hr, a.Wr = residual.shape[2:]
-        Do, Ho, Wo = min(Do, a.Dr), min(Ho, a.Hr), min(Wo, a.Wr)
-    oshape = (B, 32, Do, Ho, Wo)
-    y = ys3 = None
-    if out in ("f32", "both"):
-        y = torch.empty(oshape, device=x.device, dtype=torch.float32, memory_format=_CL3D)
-    if out in ("s3", "both"):
-        ys3 = S3Volume(_s3_alloc(oshape, x.device), oshape)
-    if y is None and ys3 is None:
-        raise ValueError("out must be 'f32', 's3' or 'both'")
-    a.x_s3, a.w_packed = x.buf.data_ptr(), packed_weight.data_ptr()
-    a.scale = None if scale is None else scale.data_ptr()
-    a.shift = None if shift is None else shift.data_ptr()
-    a.residual = None if residual is None else residual.data_ptr()
-    a.y = None if y is None else y.data_ptr()
-    a.y_s3 = None if ys3 is None else ys3.buf.data_ptr()
-    a.B, a.Cin, a.Cout = B, cin, 32
-    a.Di, a.Hi, a.Wi = Di, Hi, Wi
-    a.Do, a.Ho, a.Wo = Do, Ho, Wo
-    a.relu, a.grid = int(relu), int(grid)
-    if x.features is not None:
-        a.vol_virtual, a.vol_mask_left = 1, x.features[1]
-    work = 54.0 * cin * 32 * B * Do * Ho * Wo
-    with torch.cuda.device(x.device), _timed("conv3d_s3_bf16x3_mfma_kernel", work):
-        rc = _lib.load().dsm_conv3d_s3_fwd(ctypes.byref(a), _stream())
-    _lib.check(rc, "dsm_conv3d_s3_fwd")
-    if out == "f32":
-        return y
-    if out == "s3":
-        return ys3
-    return y, ys3
+def virtual_volume_ok(C):
+    """The z-sliding kernel can stage a virtual volume of 2C channels (C % 32 == 0) in every
+    precision except "fp32" (which has no split kernels)."""
+    return C % 32 == 0 and _OPTIONS["conv_precision"] != "fp32"
 
 
 # ----------------------------------------------------------------------------
@@ -760,10 +632,9 @@ def pack_conv2d_weight(weight, cin_padded=None):
 
 
 def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, stride=1,
-                 relu=0, k=3, dilation=1, out="f32"):
+                 relu=0, k=3, dilation=1):
     """y = relu?(conv2d(x) * scale + shift (+ residual)) on NHWC maps, "same" padding.
-    ``x``: (B, Cin, H, W) in torch.channels_last memory, Cin a multiple of 16.
-    ``out``: "f32" -> tensor; "s3" / "both" -> (also) an S3Volume (bf16x3 kernels).  Inference only."""
+    ``x``: (B, Cin, H, W) in torch.channels_last memory, Cin a multiple of 16.  Inference only."""
     _require_device("conv2d_block", x, packed_weight, scale, shift, residual)
     if not x.is_contiguous(memory_format=_CL2D):
         x = carry_amax(x.contiguous(memory_format=_CL2D), x)
@@ -778,15 +649,10 @@ def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
             residual = residual.contiguous(memory_format=_CL2D)
         a.Dr, a.Hr, a.Wr = 1, Ho, Wo
     dev = packed_weight.device
-    y = ys3 = None
-    if out in ("f32", "both"):
-        y = torch.empty((B, cout, Ho, Wo), device=dev, dtype=torch.float32, memory_format=_CL2D)
-    if out in ("s3", "both"):
-        ys3 = S3Volume(_s3_alloc((B, cout, 1, Ho, Wo), dev), (B, cout, 1, Ho, Wo))
+    y = torch.empty((B, cout, Ho, Wo), device=dev, dtype=torch.float32, memory_format=_CL2D)
     a.x = x.data_ptr()
     a.w_packed = packed_weight.data_ptr()
-    a.y = None if y is None else y.data_ptr()
-    a.y_s3 = None if ys3 is None else ys3.buf.data_ptr()
+    a.y = y.data_ptr()
     a.scale = None if scale is None else scale.data_ptr()
     a.shift = None if shift is None else shift.data_ptr()
     a.residual = None if residual is None else residual.data_ptr()
@@ -802,11 +668,7 @@ def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
         rc = _lib.load().dsm_conv3d_fwd(ctypes.byref(a), _stream())
     _lib.check(rc, "dsm_conv3d_fwd")
     del keep
-    if out == "f32":
-        return y
-    if out == "s3":
-        return ys3
-    return y, ys3
+    return y
 
 
 def warp_abs_error(left, right, disp, delt):

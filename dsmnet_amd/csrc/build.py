@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["abi.hip", "corr1d.hip", "cost_volume.hip", "soft_argmin.hip", "conv3d.hip", "conv_f16.hip",
-           "conv3d_bwd.hip", "conv_s3.hip", "bn3d.hip", "decoder.hip", "spp.hip", "warp.hip"]
+           "conv3d_bwd.hip", "bn3d.hip", "decoder.hip", "spp.hip", "warp.hip"]
 LIB = os.path.join(HERE, "libdsmnet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -37,7 +37,7 @@ def build(force=False, verbose=True, stamps=False):
         print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         return lib
-    hdrs = [os.path.join(HERE, "common.hpp"), os.path.join(HERE, "conv_split.hpp"), os.path.join(HERE, "conv_common.hpp"),
+    hdrs = [os.path.join(HERE, "common.hpp"), os.path.join(HERE, "conv_split.hpp"), os.path.join(HERE, "conv_zs.hpp"), os.path.join(HERE, "conv_common.hpp"),
             os.path.join(HERE, "..", "..", "include", "dsmnet_hip.h")]
     srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     objs = []

@@ -327,6 +327,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3d_mfma_kernel(ConvParams p) 
 }
 
 #include "conv_split.hpp"   // conv_split_kernel, deconv_split_kernel, pack_weights_split_kernel
+#include "conv_zs.hpp"      // conv_zs_kernel, pack_weights_zs_kernel
 
 // ----------------------------------------------------------------------------
 // ConvTranspose3d(k=3, stride=2, padding=1, output_padding=1), Cout = 32*NT.
@@ -877,6 +878,12 @@ size_t f16_section_bytes(int Cin, int Cout, int kd, int k) {
   return bf16x3_section_bytes(Cin, Cout, kd, k) ? 16 + (size_t)Cin * Cout * kd * 9 * 4 : 0;
 }
 
+// Conv3d(k3, s1) to 32 channels from Cin % 32 == 0 runs on the z-sliding kernel (conv_zs.hpp):
+// its split sections are packed in THAT kernel's fragment order
+bool zs_layer(int Cin, int Cout, int kd, int k, int transposed) {
+  return kd == 3 && k == 3 && !transposed && Cout == 32 && Cin % 32 == 0;
+}
+
 // the split sections behind the fp32 fragments of a packed buffer (`frag` = its first byte)
 int pack_split_sections(const float* w, char* frag, int Cin_src, int Cin, int Cout, int kd, int k,
                         int transposed, hipStream_t s) {
@@ -884,13 +891,22 @@ int pack_split_sections(const float* w, char* frag, int Cin_src, int Cin, int Co
   const long n = (long)Cin * Cout * ntaps;
   if (!bf16x3_section_bytes(Cin, Cout, kd, k)) return DSM_OK;
   char* sec2 = frag + n * 4;
+  char* sec3 = sec2 + bf16x3_section_bytes(Cin, Cout, kd, k);
+  const bool zs = zs_layer(Cin, Cout, kd, k, transposed) && Cin_src == Cin;
+  if (zs)
+    hipLaunchKernelGGL(pack_weights_zs_kernel<3>, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s, w,
+                       (unsigned short*)sec2, (const float*)nullptr, Cin);
+  else
   hipLaunchKernelGGL(pack_weights_split_kernel<3>, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s, w,
                      (unsigned short*)sec2, (const float*)nullptr, Cin, Cout, transposed, ntaps, Cin_src);
-  char* sec3 = sec2 + bf16x3_section_bytes(Cin, Cout, kd, k);
   if (hipMemsetAsync(sec3, 0, 16, s) != hipSuccess) return DSM_ERR_LAUNCH;
   const long nsrc = (long)Cin_src * Cout * ntaps;
   hipLaunchKernelGGL(absmax_kernel, dim3(dsm_cdiv(dsm_cdiv(nsrc, 4), 256) < 64 ? dsm_cdiv(dsm_cdiv(nsrc, 4), 256) : 64),
                      dim3(256), 0, s, w, nsrc, (float*)sec3);
+  if (zs)
+    hipLaunchKernelGGL(pack_weights_zs_kernel<2>, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s, w,
+                       (unsigned short*)(sec3 + 16), (const float*)sec3, Cin);
+  else
   hipLaunchKernelGGL(pack_weights_split_kernel<2>, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s, w,
                      (unsigned short*)(sec3 + 16), (const float*)sec3, Cin, Cout, transposed, ntaps, Cin_src);
   return DSM_OK;
@@ -974,7 +990,7 @@ extern "C" size_t dsm_conv_packed_weight_bytes(int Cin, int Cout, int kd, int k)
 namespace {
 
 int make_plan_f32(const dsm_conv3d_args* a, Plan* pl) {
-  DSM_REQUIRE(a && a->x && a->w_packed && (a->y || a->y_s3), DSM_ERR_ARG);
+  DSM_REQUIRE(a && a->x && a->w_packed && a->y, DSM_ERR_ARG);
   DSM_REQUIRE(a->B > 0 && a->Cin > 0 && a->Cout > 0, DSM_ERR_ARG);
   DSM_REQUIRE(a->Di > 0 && a->Hi > 0 && a->Wi > 0 && a->Do > 0 && a->Ho > 0 && a->Wo > 0,
               DSM_ERR_ARG);
@@ -983,7 +999,7 @@ int make_plan_f32(const dsm_conv3d_args* a, Plan* pl) {
   DSM_REQUIRE(a->relu >= 0 && a->relu <= 2, DSM_ERR_ARG);
   DSM_REQUIRE(a->Cin % 16 == 0, DSM_ERR_UNSUPPORTED);   // chunk sizes 8 and 16 both divide it
   DSM_REQUIRE(dsm_aligned16(a->x) && dsm_aligned16(a->w_packed) &&
-              dsm_aligned16(a->y) && dsm_aligned16(a->y_s3), DSM_ERR_ALIGN);
+              dsm_aligned16(a->y), DSM_ERR_ALIGN);
   DSM_REQUIRE(a->precision == DSM_PREC_F32 || a->precision == DSM_PREC_F16X2 || a->precision == DSM_PREC_F16, DSM_ERR_ARG);
   const int kd = a->kd ? a->kd : 3, k = a->k ? a->k : 3, dil = a->dil ? a->dil : 1;
   DSM_REQUIRE((kd == 1 || kd == 3) && (k == 1 || k == 3) && (dil == 1 || dil == 2),
@@ -1022,6 +1038,13 @@ int make_plan_f32(const dsm_conv3d_args* a, Plan* pl) {
     *pl = Plan{1, 2, NT, 1, 16, 3, 3, 1};   // (32-channel chunks measured slower: 306 vs 283 us)
     return DSM_OK;
   }
+  if (a->stride == 1 && zs_layer(a->Cin, a->Cout, kd, k, 0) && bf16x3_enabled(a) &&
+      (unsigned long)a->Hi * a->Wi * a->Cin * (a->vol_virtual ? 2ul : 4ul) < 0x7fffffffUL) {   // 32-bit offsets per input plane
+    if (a->vol_virtual) DSM_REQUIRE(a->Cin % 64 == 0, DSM_ERR_UNSUPPORTED);   // [left | right], 32-channel groups each
+    *pl = Plan{7, 1, 1, 2, 32, 3, 3, 1};
+    return DSM_OK;
+  }
+  DSM_REQUIRE(!a->vol_virtual, DSM_ERR_UNSUPPORTED);   // only the z-sliding kernel stages a virtual volume
   const bool big = (long)a->B * a->Do * dsm_cdiv(a->Ho, 8) * dsm_cdiv(a->Wo, 32) >= 1024;
   if (a->stride == 1 && k == 3 && bf16x3_enabled(a) && bf16x3_section_bytes(a->Cin, a->Cout, kd, k) &&
       4l * a->B * a->Di * a->Hi * a->Wi * a->Cin < 0x80000000l) {       // OOBV must lie past the tensor
@@ -1084,9 +1107,8 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
   const int rc = make_plan_f32(a, pl);
   if (rc != DSM_OK) return rc;
   pl->pm = 3;
-  if ((pl->kind == 5 || pl->kind == 6) && a->precision != DSM_PREC_F32) {
+  if ((pl->kind == 5 || pl->kind == 6 || pl->kind == 7) && a->precision != DSM_PREC_F32) {
     DSM_REQUIRE(a->x_amax != nullptr, DSM_ERR_ARG);      // the input's absolute maximum (device scalar)
-    DSM_REQUIRE(!a->y_s3, DSM_ERR_UNSUPPORTED);          // S3 is the bf16x3 hand-over format
     pl->pm = a->precision == DSM_PREC_F16X2 ? 2 : 1;
   }
   return DSM_OK;
@@ -1116,6 +1138,7 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
       else snprintf(buf, len, "conv2d_%s_mfma_kernel<NT=%d,TM=%d,DIL=%d>", pr, pl.NT, pl.TM, pl.DIL);
       break;
     }
+    case 7: snprintf(buf, len, "conv3d_zs_%s_mfma_kernel%s", pl.pm == 3 ? "bf16x3" : (pl.pm == 2 ? "f16x2" : "f16"), a->vol_virtual ? "<vol>" : ""); break;
     case 6: snprintf(buf, len, "deconv3d_%s_mfma_kernel<NT=%d>", pl.pm == 3 ? "bf16x3" : (pl.pm == 2 ? "f16x2" : "f16"), pl.NT); break;
     default: snprintf(buf, len, "deconv3d_cout1_kernel"); break;
   }
@@ -1126,19 +1149,33 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   Plan pl;
   int rc = make_plan(a, &pl);
   if (rc != DSM_OK) return rc;
-  // the S3 second output exists in the epilogue of the bf16x3 kernels only; an S3 input is
-  // understood by the bf16x3 convolution (not the transposed one) only
-  if (a->y_s3) DSM_REQUIRE(pl.kind == 5 || pl.kind == 6, DSM_ERR_UNSUPPORTED);
   ConvParams p;
   p.x = (const float*)a->x; p.w = (const float*)a->w_packed; p.scale = a->scale;
   p.x_amax = a->x_amax; p.w_amax = nullptr; p.y_amax = a->y_amax;
   p.shift = a->shift; p.res = (const float*)a->residual; p.y = (float*)a->y;
-  p.ys3 = (unsigned char*)a->y_s3;
   p.force_blocks = (a->flags >> DSM_CONV_BLOCKS_SHIFT) & 0xffff;
   p.B = a->B; p.Cin = a->Cin; p.Cout = a->Cout;
   p.Di = a->Di; p.Hi = a->Hi; p.Wi = a->Wi; p.Do = a->Do; p.Ho = a->Ho; p.Wo = a->Wo;
   p.Dr = a->Dr; p.Hr = a->Hr; p.Wr = a->Wr; p.relu = a->relu;
   p.ntx = p.nty = p.ntiles = 0;
+  if (pl.kind == 7) {
+    ZsParams z;
+    const size_t n = (size_t)a->Cin * 32 * 27;
+    const char* sec2 = (const char*)a->w_packed + n * 4;
+    const char* sec3 = sec2 + n * 6;
+    z.x = (const float*)a->x; z.scale = a->scale; z.shift = a->shift; z.res = (const float*)a->residual;
+    z.y = (float*)a->y; z.x_amax = a->x_amax; z.y_amax = a->y_amax;
+    z.w_amax = pl.pm == 3 ? nullptr : (const float*)sec3;
+    z.w = (const unsigned char*)(pl.pm == 3 ? sec2 : sec3 + 16);
+    z.wbytes = (unsigned)(pl.pm == 3 ? n * 6 : n * 4);
+    z.B = a->B; z.Cin = a->Cin;
+    z.Di = a->Di; z.Hi = a->Hi; z.Wi = a->Wi; z.Do = a->Do; z.Ho = a->Ho; z.Wo = a->Wo;
+    z.Dr = a->Dr; z.Hr = a->Hr; z.Wr = a->Wr; z.relu = a->relu;
+    z.vol = a->vol_virtual ? 1 : 0; z.vol_mask_left = a->vol_mask_left ? 1 : 0;
+    dsm_clear_stale_error();
+    if (pl.pm == 3) return launch_conv_zs<3>(z, p.force_blocks, (hipStream_t)stream);
+    return dsmk::run_zs_f16(pl.pm, z, p.force_blocks, (hipStream_t)stream);
+  }
   {
     const unsigned long xb = 4ul * a->B * a->Di * a->Hi * a->Wi * a->Cin;
     const int kd_ = a->kd ? a->kd : 3, k_ = a->k ? a->k : 3;

@@ -9,7 +9,6 @@ namespace dsmk {
 struct ConvParams {
   const float* x; const float* w; const float* scale; const float* shift;
   const float* res; float* y;
-  unsigned char* ys3;         // optional second output in the S3 format (conv_s3.hip); bf16x3 kernels only
   int force_blocks;           // 0, or the persistent grid size asked for in dsm_conv3d_args.flags
   int B, Cin, Cout;
   int Di, Hi, Wi, Do, Ho, Wo, Dr, Hr, Wr;
@@ -25,11 +24,30 @@ struct ConvParams {
 };
 
 // One place decides the kernel variant; dsm_conv3d_fwd launches it, dsm_conv3d_plan names it.
-// kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1, 4 conv cout1 z-sliding, 5 conv split (bf16x3 / f16x2 / f16), 6 deconv split
+// kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1, 4 conv cout1 z-sliding, 5 conv split (bf16x3 / f16x2 / f16), 6 deconv split,
+//       7 z-sliding conv (Cout = 32, stride 1; conv_zs.hpp)
 struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; int nsplit = 1; int pm = 3; };
 
-// conv_f16.hip: the fp16 split kernels (plan kinds 5 / 6 with pm = 2 | 1)
+// the z-sliding kernel (conv_zs.hpp, plan kind 7)
+struct ZsParams {
+  const float* x;               // fp32 NDHWC (B,Di,Hi,Wi,Cin), or (vol) the NHWC features (2B,Hi,Wi,Cin/2)
+  const unsigned char* w;       // packed by pack_weights_zs_kernel<PM> (past the header)
+  const float* scale; const float* shift;
+  const float* res;             // fp32 NDHWC (B,Dr,Hr,Wr,32) or null
+  float* y;                     // fp32 NDHWC (B,Do,Ho,Wo,32)
+  const float* x_amax; const float* w_amax; float* y_amax;
+  int B, Cin;
+  int Di, Hi, Wi, Do, Ho, Wo, Dr, Hr, Wr;
+  int relu;
+  int vol, vol_mask_left;
+  int ntx, nty, ncol;           // columns: (b, ty, tx), 8 x 32 outputs each
+  long nunits;                  // ncol * Do
+  unsigned wbytes;
+};
+
+// conv_f16.hip: the fp16 kernels (plan kinds 5 / 6 / 7 with pm = 2 | 1)
 __attribute__((visibility("hidden"))) int run_split_f16(const Plan& pl, const ConvParams& p, hipStream_t s);
+__attribute__((visibility("hidden"))) int run_zs_f16(int pm, const ZsParams& p, int grid, hipStream_t s);
 
 }  // namespace dsmk
 
@@ -37,6 +55,7 @@ namespace {
 
 using dsmk::ConvParams;
 using dsmk::Plan;
+using dsmk::ZsParams;
 
 // Compile-time loop: f(integral_constant<int, I>) for I in [I0, N).  Used where an index must
 // be a constant expression so that accumulator arrays stay in registers (a runtime-indexed
@@ -160,61 +179,6 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const Affine& af, 
     *reinterpret_cast<f32x4*>(yv + 8 * g) = v;
     track_amax(am, v);
   }
-}
-
-// The same epilogue, the result also (or only) written in the S3 format of conv_s3.hip -- fp32
-// pre-split into three bf16 planes, [..][y][cg][plane][g][x][8] -- so that a z-sliding bf16x3
-// consumer needs no operand split.  Lane (r, h) of a 32x32 tile owns channels 8 q + 4 h + (0..3)
-// of its voxel (register quads q = 0..3), i.e. exactly the units g = h (quads 0, 2) and g = 2 + h
-// (quads 1, 3) of the voxel's 32-channel group: two 16-byte stores per plane.
-// `s3row`: the (voxel row, channel group) row-set, 12 rows of `Wo` units; `xo`: this lane's column.
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned s3_pack_bf16(float a, float b) {
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-  const f2 t = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(t, b2));
-}
-__device__ __forceinline__ void s3_store_unit(const f32x4 lo4, const f32x4 hi4, unsigned char* o, long plane_stride) {
-  float r[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    unsigned u[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      u[i] = s3_pack_bf16(r[2 * i], r[2 * i + 1]);
-      if (k < 2) {
-        r[2 * i] -= __builtin_bit_cast(float, u[i] << 16);
-        r[2 * i + 1] -= __builtin_bit_cast(float, u[i] & 0xffff0000u);
-      }
-    }
-    *reinterpret_cast<u32x4_t*>(o + k * plane_stride) = u32x4_t{u[0], u[1], u[2], u[3]};
-  }
-}
-template <int COUT>
-__device__ __forceinline__ void store_tile_s3(const f32x16& acc, const Affine& af, int relu,
-                                              float* __restrict__ yv, const float* __restrict__ rv,
-                                              unsigned char* __restrict__ s3row, int xo, int Wo, int h, float& am) {
-  f32x4 r4[4], v4[4];
-  if (rv) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) r4[g] = *reinterpret_cast<const f32x4*>(rv + 8 * g);
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const f32x4 sc = af.sc[g], sh = af.sh[g];
-    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-    v = v * sc + sh;
-    if (relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (rv) v += r4[g];
-    if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (yv) *reinterpret_cast<f32x4*>(yv + 8 * g) = v;
-    v4[g] = v;
-    track_amax(am, v);
-  }
-  const long ps = 4l * Wo * 16;
-  s3_store_unit(v4[0], v4[2], s3row + ((long)h * Wo + xo) * 16, ps);
-  s3_store_unit(v4[1], v4[3], s3row + ((long)(2 + h) * Wo + xo) * 16, ps);
 }
 
 // ----------------------------------------------------------------------------

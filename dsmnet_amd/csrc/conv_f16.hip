@@ -12,7 +12,14 @@
 
 namespace {
 #include "conv_split.hpp"
+#include "conv_zs.hpp"
 }  // namespace
+
+int dsmk::run_zs_f16(int pm, const ZsParams& p, int grid, hipStream_t s) {
+  if (pm == 2) return launch_conv_zs<2>(p, grid, s);
+  if (pm == 1) return launch_conv_zs<1>(p, grid, s);
+  return DSM_ERR_UNSUPPORTED;
+}
 
 int dsmk::run_split_f16(const Plan& pl, const ConvParams& p, hipStream_t s) {
   if (pl.pm == 2) return dispatch_split<2>(pl, p, s);

@@ -431,12 +431,6 @@ void conv_split_kernel(ConvParams p) {
           if (yo >= p.Ho || xo >= p.Wo) continue;
           const long vox = (((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo;
           const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
-          if (PM == 3 && p.ys3)
-            store_tile_s3<COUT>(acc[m][n], af, p.relu, p.y ? p.y + vox * COUT + cbase : nullptr,
-                                p.res ? p.res + rvox * COUT + cbase : nullptr,
-                                p.ys3 + (((((long)tb * p.Do + tz) * p.Ho + yo) * NTP + n0 + n) * 12) * p.Wo * 16,
-                                xo, p.Wo, h, am);
-          else
           store_tile<COUT>(acc[m][n], af, p.relu, p.y + vox * COUT + cbase,
                            p.res ? p.res + rvox * COUT + cbase : nullptr, am);
         }
@@ -668,12 +662,6 @@ __global__ __launch_bounds__(NTHREADS, (DeconvSplitCfg<PM, NT>::WGS)) void decon
             if (yo >= p.Ho || xo >= p.Wo) continue;
             const long vox = (((long)cur_pos.b * p.Do + zo) * p.Ho + yo) * p.Wo + xo;
             const long rvox = (((long)cur_pos.b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo;
-            if (PM == 3 && p.ys3)
-              store_tile_s3<COUT>(acc[c][n], af, p.relu, p.y ? p.y + vox * COUT + cbase : nullptr,
-                                  p.res ? p.res + rvox * COUT + cbase : nullptr,
-                                  p.ys3 + (((((long)cur_pos.b * p.Do + zo) * p.Ho + yo) * NT + n) * 12) * p.Wo * 16,
-                                  xo, p.Wo, h, am);
-            else
             store_tile<COUT>(acc[c][n], af, p.relu, p.y + vox * COUT + cbase,
                              p.res ? p.res + rvox * COUT + cbase : nullptr, am);
           }

@@ -63,9 +63,9 @@ class feature3d(nn.Module):
     def cost(self, x, virtual=None):
         """x18 -> x37, the (B,1,2D,2h,2w) cost.  Skip additions are fused into the
         transposed convolutions (relu(bn(deconv)) + skip, cropped: gcnet.py:78-96).
-        ``virtual``: the same volume as a never-materialised ``S3Volume`` (eval): l19 (64 -> 32)
-        then stages it from the split feature maps on the z-sliding kernel and hands l20 its
-        result pre-split; the fp32 volume ``x`` still feeds the stride-2 l21."""
+        ``virtual``: the same volume as a never-materialised ``costvolume.VirtualVolume`` (eval):
+        l19 (64 -> 32) then stages it from the towers' output on the z-sliding kernel; the fp32
+        volume ``x`` still feeds the stride-2 l21."""
         x21 = self.l21(x)
         x24 = self.l24(x21)
         x27 = self.l27(x24)
@@ -73,10 +73,7 @@ class feature3d(nn.Module):
         x33 = self.l33(x32, residual=self.l29(self.l28(x27)))
         x34 = self.l34(x33, residual=self.l26(self.l25(x24)))
         x35 = self.l35(x34, residual=self.l23(self.l22(x21)))
-        if virtual is not None and self.l19.eats_s3() and self.l20.eats_s3():
-            x20 = self.l20(self.l19(virtual, out="s3"))
-        else:
-            x20 = self.l20(self.l19(x))
+        x20 = self.l20(self.l19(x if virtual is None else virtual))
         x36 = self.l36(x35, residual=x20)
         return self.l37(x36)
 
@@ -99,6 +96,7 @@ class gcnet(nn.Module):
         if self.training:
             return self.layer2d(imL), self.layer2d(imR)
         both = self.layer2d(torch.cat([imL, imR], dim=0))     # eval: BN uses running stats
+        self.__dict__["_both"] = both
         return cv.carry_amax(both[: imL.shape[0]], both), cv.carry_amax(both[imL.shape[0]:], both)
 
     def forward(self, imL, imR, mode="train"):
@@ -108,12 +106,14 @@ class gcnet(nn.Module):
     def _forward(self, imL, imR, mode):
         if imL.shape != imR.shape:
             raise ValueError("gcnet: imL and imR must have the same shape")   # gcnet.py:127
+        self.__dict__["_both"] = None
         fL, fR = self.features(imL, imR)
+        both = self.__dict__.pop("_both")
         xL = cv.concat_volume(fL, fR, self.D, mask_left=False)
         virtual = None
-        if (cv.get_option("s3") and cv.get_option("fuse_volume") and cv.get_option_bf16x3()
-                and not self.training and not torch.is_grad_enabled() and fL.shape[1] % 32 == 0):
-            virtual = cv.concat_volume_s3(fL, fR, self.D, False, materialise=False)
+        if (both is not None and both.is_cuda and cv.get_option("fuse_volume") and
+                not torch.is_grad_enabled() and cv.virtual_volume_ok(both.shape[1])):
+            virtual = cv.VirtualVolume(both, self.D, False)
         oL = self.layer3d(xL, mode, virtual)[:, :, : imL.shape[-2], : imL.shape[-1]]
         return [0], [oL]
 

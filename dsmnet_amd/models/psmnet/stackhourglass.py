@@ -40,15 +40,14 @@ class hourglass(nn.Module):
         self.conv5 = _deconvbn_3d(c * 2, c * 2)     # + presqu / pre
         self.conv6 = _deconvbn_3d(c * 2, c)         # + x
 
-    def forward(self, x, presqu, postsqu, skip=None, out_format="f32"):
+    def forward(self, x, presqu, postsqu, skip=None):
         """Reference signature plus ``skip``: when given, ``out + skip`` (the caller's
-        ``myadd_3d(out, cost0)``, stackhourglass.py:139-145) is fused into conv6;
-        ``out_format`` ("f32" | "s3" | "both"): the format(s) conv6 writes ``out`` in (eval, bf16x3)."""
+        ``myadd_3d(out, cost0)``, stackhourglass.py:139-145) is fused into conv6."""
         out = self.conv1(x)                                    # 1/4 -> 1/8
         pre = self.conv2(out, residual=postsqu, relu=True)     # relu(conv2 (+ postsqu))
         out = self.conv4(self.conv3(pre))                      # 1/8 -> 1/16
         post = self.conv5(out, residual=presqu if presqu is not None else pre, relu=True)
-        return self.conv6(post, residual=skip, out=out_format), pre, post      # 1/8 -> 1/4
+        return self.conv6(post, residual=skip), pre, post      # 1/8 -> 1/4
 
 
 class PSMNet(nn.Module):
@@ -101,38 +100,20 @@ class PSMNet(nn.Module):
             both = fe(cv.stage_images_nhwc16(left, right), staged=True)
         else:
             both = self.feature_extraction(torch.cat([left, right], dim=0))
+        self.__dict__["_both"] = both            # the two views as one NHWC tensor (virtual volume)
         return (cv.carry_amax(both[: left.shape[0]], both), cv.carry_amax(both[left.shape[0]:], both))
-
-    def _s3_path(self):
-        """Eval mode without autograd: the 32-channel full-resolution layers (dres0, dres1,
-        classif*.0 -- 82 % of the trunk's FLOPs) run on the z-sliding S3 kernel, their inputs
-        handed over pre-split by the layer before."""
-        return (cv.get_option("s3") and cv.get_option_bf16x3() and not self.training and
-                not torch.is_grad_enabled())
 
     def regularise(self, cost):
         """3-D trunk (stackhourglass.py:135-149): volume -> the three head costs.  ``cost``: the
-        volume as an fp32 tensor or (eval) an ``S3Volume``, possibly virtual."""
-        if not self._s3_path():
-            cost0 = self.dres0(cost)
-            cost0 = self.dres1(cost0, residual=cost0)
-            out1, pre1, post1 = self.dres2(cost0, None, None, skip=cost0)
-            out2, pre2, post2 = self.dres3(out1, pre1, post1, skip=cost0)
-            out3, pre3, post3 = self.dres4(out2, pre1, post2, skip=cost0)    # pre1, as the reference (:144)
-            cost1 = self.classif1(out1)
-            cost2 = self.classif2(out2, residual=cost1)
-            cost3 = self.classif3(out3, residual=cost2)
-            return cost1, cost2, cost3
-        # same dataflow; tensors that feed an S3 layer travel as S3 (".s"), those that feed the
-        # fp32 kernels (stride-2 convolutions, skip additions) as fp32 (".f")
-        c0a_f, c0a_s = self.dres0(cost, out="both")
-        cost0 = self.dres1(c0a_s, residual=c0a_f)
-        (o1_f, o1_s), pre1, post1 = self.dres2(cost0, None, None, skip=cost0, out_format="both")
-        (o2_f, o2_s), pre2, post2 = self.dres3(o1_f, pre1, post1, skip=cost0, out_format="both")
-        o3_s, pre3, post3 = self.dres4(o2_f, pre1, post2, skip=cost0, out_format="s3")
-        cost1 = self.classif1(o1_s)
-        cost2 = self.classif2(o2_s, residual=cost1)
-        cost3 = self.classif3(o3_s, residual=cost2)
+        volume as an fp32 tensor or (eval) a never-materialised ``costvolume.VirtualVolume``."""
+        cost0 = self.dres0(cost)
+        cost0 = self.dres1(cost0, residual=cost0)
+        out1, pre1, post1 = self.dres2(cost0, None, None, skip=cost0)
+        out2, pre2, post2 = self.dres3(out1, pre1, post1, skip=cost0)
+        out3, pre3, post3 = self.dres4(out2, pre1, post2, skip=cost0)    # pre1, as the reference (:144)
+        cost1 = self.classif1(out1)
+        cost2 = self.classif2(out2, residual=cost1)
+        cost3 = self.classif3(out3, residual=cost2)
         return cost1, cost2, cost3
 
     def forward(self, left, right, mode="train"):
@@ -140,12 +121,14 @@ class PSMNet(nn.Module):
             return self._forward(left, right)
 
     def _forward(self, left, right):
+        self.__dict__["_both"] = None
         refimg_fea, targetimg_fea = self.features(left, right)
-        if self._s3_path() and cv.get_option("fuse_volume"):
-            # the volume is never written: dres0's first convolution stages it from the split
-            # feature maps (shift by d, mask x < d: stackhourglass.py:124-133)
-            cost = cv.concat_volume_s3(refimg_fea, targetimg_fea, self.maxdisp // 4, True,
-                                       materialise=False)
+        both = self.__dict__.pop("_both")
+        if (both is not None and cv.get_option("fuse_volume") and not torch.is_grad_enabled() and
+                cv.virtual_volume_ok(both.shape[1])):
+            # the volume is never written: dres0's first convolution (the z-sliding kernel) stages
+            # plane d from the towers' output (shift by d, mask x < d: stackhourglass.py:124-133)
+            cost = cv.VirtualVolume(both, self.maxdisp // 4, True)
         else:
             cost = cv.concat_volume(refimg_fea, targetimg_fea, self.maxdisp // 4, mask_left=True)
         size = (self.maxdisp, left.shape[2], left.shape[3])

@@ -149,10 +149,6 @@ typedef struct dsm_conv3d_args {
   int kd;                 /* depth taps: 3 (default) or 1            */
   int k;                  /* taps in y and x: 3 (default) or 1       */
   int dil;                /* dilation in y and x: 1 (default) or 2   */
-  /* ABI v4: optional second output, the same result in the S3 format (see below) for a following
-   * dsm_conv3d_s3_fwd; `y` may then be NULL.  Only the bf16x3 3-D kernels have this epilogue
-   * (Conv3d / ConvTranspose3d with Cout in {32, 64}); DSM_ERR_UNSUPPORTED otherwise. */
-  void*        y_s3;
   /* ABI v4: tuning / A-B switches of THIS call (0 = the plan's own choice).  The library reads no
    * environment variable and holds no global switch: a plan is a pure function of the arguments. */
   int          flags;
@@ -167,6 +163,15 @@ typedef struct dsm_conv3d_args {
    * float bits: the caller zeroes it (on the stream) before the launch.  Any precision, every MFMA
    * kernel (Cout >= 32). */
   float*       y_amax;
+  /* ABI v6: vol_virtual = 1 -- the input is a concatenation cost volume that is NEVER MATERIALISED
+   * (models/psmnet/stackhourglass.py:124-133 with vol_mask_left = 1, models/gcnet.py:130-135 with 0,
+   * fused into the first 3-D convolution).  `x` is then the NHWC feature tensor (2B, Hi, Wi, Cin/2)
+   * [the B left maps, then the B right maps]; input plane d of the (B, Cin, Di, Hi, Wi) volume is
+   * staged as [left | right shifted by d voxels] with x < d zeroed (right half always, left half
+   * iff vol_mask_left); Di = the number of disparity planes.  Conv3d(k3, s1) to 32 channels only
+   * (the z-sliding kernel, "conv3d_zs_..."): DSM_ERR_UNSUPPORTED otherwise.  x_amax: of the features. */
+  int          vol_virtual;
+  int          vol_mask_left;
 } dsm_conv3d_args;
 /* fp32 operands, fp32-accurate products and sums: three-term bf16 split (six bf16 MFMAs per
  * product) or, with DSM_CONV_FP32_MFMA, the fp32-input MFMA */
@@ -251,71 +256,6 @@ int dsm_conv3d_cout1_bwd(const void* x, const void* g, const void* w_packed, voi
 int dsm_deconv3d_cout1_bwd(const void* x, const void* g, const void* w, void* dx, void* dw,
                            int B, int C, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                            dsm_stream_t stream);
-
-/* ---------------------------------------------------------------------------
- * "S3" activations: fp32 stored pre-split for the bf16 matrix pipe (ABI v4).
- * Every value v is kept as the three bf16 terms of its exact split v = hi + mid + lo
- * (round-to-nearest; lossless for normal fp32 values), 6 bytes per value, in the operand order
- * of v_mfma_f32_16x16x32_bf16:
- *     [b][z][y][cg = c/32][plane 0..2 = hi,mid,lo][g = 0..3][x][e = 0..7]      (bf16)
- *     element e of unit g of group cg = channel 32 cg + 16 (e >> 2) + 4 g + (e & 3)
- * It is a storage format of the SAME fp32 tensor (dsm_s3_to_ndhwc returns it bit for bit): the
- * layer that produces an activation splits it once, in its epilogue, instead of every consumer
- * splitting it per tap inside its MFMA stream.  C % 32 == 0.
- * ------------------------------------------------------------------------- */
-size_t dsm_s3_bytes(int B, int C, int D, int H, int W);
-int dsm_s3_from_ndhwc(const void* x_f32_ndhwc, void* s3, int B, int C, int D, int H, int W,
-                      dsm_stream_t stream);
-int dsm_s3_to_ndhwc(const void* s3, void* x_f32_ndhwc, int B, int C, int D, int H, int W,
-                    dsm_stream_t stream);
-
-/* (a2,a3) the concatenation cost volume written as S3 -- same semantics as
- * dsm_concat_volume_fwd (models/gcnet.py:130-135, models/psmnet/stackhourglass.py:124-133).
- * fL, fR: (B,C,H,W) NCHW fp32; vol: S3 of (B,2C,D,H,W); scratch: dsm_concat_volume_s3_scratch_bytes
- * bytes (the split features).  Written in one pass, no memset. */
-size_t dsm_concat_volume_s3_scratch_bytes(int B, int C, int H, int W);
-int dsm_concat_volume_s3_fwd(const void* fL, const void* fR, void* scratch, void* vol,
-                             int B, int C, int H, int W, int D, int mask_left,
-                             dsm_stream_t stream);
-
-/* (a5) Conv3d(k3, s1, p1), Cin % 32 == 0 -> Cout = 32 on S3 input: the z-sliding bf16x3 kernel
- * (dsmnet_amd/csrc/conv_s3.hip).  Replaces convbn_3d (+ReLU, +myadd_3d) of
- * models/psmnet/submodule.py:16-19, stackhourglass.py:10-20,73-98,135-149 for the 32-channel
- * full-resolution layers.  Epilogue as dsm_conv3d_fwd (scale/shift/residual/relu); the result is
- * written as fp32 NDHWC (`y`), as S3 (`y_s3`), or both.  `residual` is fp32 NDHWC.
- * (Do,Ho,Wo) <= (Di,Hi,Wi): only that corner is computed (the crop of myadd_3d). */
-typedef struct dsm_conv3d_s3_args {
-  const void*  x_s3;      /* S3 of (B,Di,Hi,Wi,Cin)                              */
-  const void*  w_packed;  /* from dsm_conv3d_s3_pack_weights                      */
-  const float* scale;     /* [32] or NULL (= 1)                                   */
-  const float* shift;     /* [32] or NULL (= 0)                                   */
-  const void*  residual;  /* fp32 (B,Dr,Hr,Wr,32) NDHWC or NULL                   */
-  void*        y;         /* fp32 (B,Do,Ho,Wo,32) NDHWC or NULL                   */
-  void*        y_s3;      /* S3 of (B,Do,Ho,Wo,32) or NULL                        */
-  int B, Cin, Cout;
-  int Di, Hi, Wi;
-  int Do, Ho, Wo;
-  int Dr, Hr, Wr;
-  int relu;               /* 0 none, 1 after the skip add, 2 before it            */
-  int grid;               /* persistent workgroups; 0 = one per CU (256)          */
-  /* vol_virtual = 1: the input is a concatenation cost volume that is NEVER MATERIALISED.
-   * x_s3 is then the buffer written by dsm_features_s3 (the split feature maps, S3 of
-   * (B, Cin = 2C, 1, Hi, Wi) with channel groups [left | right]); input plane d is staged as
-   * that plane with the right half shifted by d voxels and x < d zeroed (right half always,
-   * left half iff vol_mask_left) -- stackhourglass.py:124-133 / gcnet.py:130-135 fused into
-   * the first 3-D convolution.  Di = the number of disparity planes. */
-  int vol_virtual;
-  int vol_mask_left;
-} dsm_conv3d_s3_args;
-/* split feature maps for a virtual volume: fL, fR (B,C,H,W) NCHW fp32 -> fs,
- * dsm_concat_volume_s3_scratch_bytes(B,C,H,W) bytes. */
-int dsm_features_s3(const void* fL, const void* fR, void* fs, int B, int C, int H, int W,
-                    dsm_stream_t stream);
-size_t dsm_conv3d_s3_packed_weight_bytes(int Cin, int Cout);
-/* w_torch: (32, Cin, 3,3,3) fp32 */
-int dsm_conv3d_s3_pack_weights(const void* w_torch, void* w_packed, int Cin, int Cout,
-                               dsm_stream_t stream);
-int dsm_conv3d_s3_fwd(const dsm_conv3d_s3_args* args, dsm_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Train-mode BatchNorm3d + cropped skip addition + ReLU on NDHWC fp32 volumes, forward and

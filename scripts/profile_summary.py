@@ -10,7 +10,7 @@ tag, stats_csv, bench_json, prof_json = sys.argv[1:5]
 bench = json.load(open(bench_json))
 prof = json.load(open(prof_json))
 rows = list(csv.DictReader(open(stats_csv)))
-OURS = ("conv3d_mfma", "conv_bf16x3", "deconv_bf16x3", "deconv3d", "cout1", "soft_argmin", "volume_", "pack_weights", "spp_", "corr1d", "warp_", "conv_s3", "feat_s3", "s3_from", "s3_to", "bn_")
+OURS = ("conv3d_mfma", "conv_split", "deconv_split", "conv_zs", "deconv3d", "cout1", "soft_argmin", "volume_", "pack_weights", "absmax", "spp_", "corr1d", "box_filter", "warp_", "stage_pair", "decoder_cat", "bn_")
 
 
 def short(n):
@@ -25,23 +25,25 @@ def plan_name(n):
         S, NT, TM, CK, KZ, K, DIL = map(int, m.groups())
         return ("conv3d_mfma_kernel<S=%d,NT=%d,TM=%d,CK=%d>" % (S, NT, TM, CK) if KZ == 3 else
                 "conv2d_mfma_kernel<S=%d,NT=%d,TM=%d,K=%d,DIL=%d>" % (S, NT, TM, K, DIL))
-    if n.startswith("conv_s3_kernel"):
-        return "conv3d_s3_bf16x3_mfma_kernel"
-    m = re.match(r"conv_bf16x3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:false|true))?(?:, (\d+))?>", n)
+    PR = {"3": "bf16x3", "2": "f16x2", "1": "f16"}
+    m = re.match(r"conv_zs_kernel<(\d+)>", n)
     if m:
-        NT, TM, KZ, DIL, S = map(int, m.groups()[:5])
-        nsplit = int(m.group(6) or 1)
+        return "conv3d_zs_%s_mfma_kernel" % PR[m.group(1)]      # (the <vol> launch shares the symbol)
+    m = re.match(r"conv_split_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", n)
+    if m:
+        PM, NT, TM, KZ, DIL, S, nsplit = m.groups()
+        pr, NT, TM, KZ, DIL, S, nsplit = PR[PM], int(NT), int(TM), int(KZ), int(DIL), int(S), int(nsplit)
         if nsplit > 1 and KZ == 3:
-            return "conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>x%d" % (NT, TM, nsplit)
+            return "conv3d_%s_mfma_kernel<NT=%d,TM=%d>x%d" % (pr, NT, TM, nsplit)
         if nsplit > 1:
-            return "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>x%d" % (NT, TM, DIL, nsplit)
+            return "conv2d_%s_mfma_kernel<NT=%d,TM=%d,DIL=%d>x%d" % (pr, NT, TM, DIL, nsplit)
         if S == 2:
-            return "conv3d_bf16x3_mfma_kernel<S=2,NT=%d,TM=%d>" % (NT, TM)
-        return ("conv3d_bf16x3_mfma_kernel<NT=%d,TM=%d>" % (NT, TM) if KZ == 3 else
-                "conv2d_bf16x3_mfma_kernel<NT=%d,TM=%d,DIL=%d>" % (NT, TM, DIL))
-    m = re.match(r"deconv_bf16x3_kernel<(\d+)>", n)
+            return "conv3d_%s_mfma_kernel<S=2,NT=%d,TM=%d>" % (pr, NT, TM)
+        return ("conv3d_%s_mfma_kernel<NT=%d,TM=%d>" % (pr, NT, TM) if KZ == 3 else
+                "conv2d_%s_mfma_kernel<NT=%d,TM=%d,DIL=%d>" % (pr, NT, TM, DIL))
+    m = re.match(r"deconv_split_kernel<(\d+), (\d+)>", n)
     if m:
-        return "deconv3d_bf16x3_mfma_kernel<NT=%s>" % m.group(1)
+        return "deconv3d_%s_mfma_kernel<NT=%s>" % (PR[m.group(1)], m.group(2))
     m = re.match(r"deconv3d_mfma_kernel<(\d+), (\d+)>", n)
     if m:
         return "deconv3d_mfma_kernel<NT=%s,CK=%s>" % m.groups()
@@ -70,9 +72,9 @@ for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"])):
 d = bench["roofline"]
 print("\nDominant kernel `%s`: %.1f %s = %.1f %% of the %.1f peak (%d launches/step, %.2f ms/step)."
       % (d["kernel"], d["achieved"], d["unit"], 100 * d["frac"], d["peak"], d["launches_per_step"], d["ms_per_step"]))
-if "bf16_mfma_tflops_executed" in d:
-    print("That peak is the dense bf16 MFMA peak (%.0f TF/s) / 6 MFMAs per fp32 product; executed bf16 MFMA rate %.0f TF/s; "
-          "%.2fx the fp32-input MFMA peak (157.3 TF/s) in algorithmic fp32 FLOP/s." % (d["bf16_mfma_peak"], d["bf16_mfma_tflops_executed"], d["x_fp32_mfma_peak"]))
+if "mfma_tflops_executed" in d:
+    print("That peak is the dense 16-bit MFMA peak (%.0f TF/s) / %d MFMAs per fp32 product (%s); executed MFMA rate %.0f TF/s; "
+          "%.2fx the fp32-input MFMA peak (157.3 TF/s) in algorithmic fp32 FLOP/s." % (d["mfma_peak_16bit"], d["mfmas_per_product"], d["mfma_dtype"], d["mfma_tflops_executed"], d["x_fp32_mfma_peak"]))
 v = bench.get("cost_volume_build")
 if v:
     print("Cost-volume build (the default forward no longer launches it; measured in the same model's materialising path): %.1f us -> %.0f GB/s = %.1f %% of 8 TB/s (north-star target >= 60 %%), %.1f %% of the 6.29 TB/s copy ceiling; back to back %.1f us = %.1f %%; %.1f MB algorithmic."

@@ -59,7 +59,7 @@ def test_argument_validation_returns_codes(hip_lib):
     assert hip_lib.dsm_conv3d_packed_weight_bytes(128, 128, 0) == 128 * 128 * 27 * 4      # no bf16x3 variant
     assert hip_lib.dsm_conv_packed_weight_bytes(128, 128, 1, 3) == 128 * 128 * 9 * (4 + 6 + 4) + 16
     assert hip_lib.dsm_conv_packed_weight_bytes(128, 32, 1, 1) == 128 * 32 * 4
-    # ABI v5: weight gradients (flags argument), the 2-D entry point, the S3 kernel's tiling field
+    # ABI v5: weight gradients (flags argument), the 2-D entry point
     assert hip_lib.dsm_conv3d_wgrad(null, one, one, one, 1, 32, 32, 4, 4, 4, 4, 4, 4, 1, 0, null) == -1
     assert hip_lib.dsm_conv3d_wgrad(one, one, one, one, 1, 32, 48, 4, 4, 4, 4, 4, 4, 1, 0, null) == -2   # Cg % 32
     assert hip_lib.dsm_conv3d_wgrad(one, one, one, one, 1, 32, 32, 4, 4, 4, 4, 4, 4, 3, 0, null) == -2   # stride
@@ -67,12 +67,6 @@ def test_argument_validation_returns_codes(hip_lib):
     assert hip_lib.dsm_conv2d_wgrad(one, one, one, one, 1, 32, 32, 8, 8, 4, 4, 2, 2, 0, null) == -2      # stride 2 + dilation 2
     assert hip_lib.dsm_conv2d_wgrad(one, one, one, one, 1, 24, 32, 8, 8, 8, 8, 1, 1, 0, null) == -2      # Cx % 32
     assert hip_lib.dsm_conv2d_wgrad(ctypes.c_void_p(20), one, one, one, 1, 32, 32, 8, 8, 8, 8, 1, 1, 0, null) == -4
-    s3 = _lib.Conv3dS3Args()
-    s3.x_s3 = s3.w_packed = s3.y = 16
-    s3.B, s3.Cin, s3.Cout = 1, 32, 32
-    s3.Di = s3.Hi = s3.Wi = s3.Do = s3.Ho = s3.Wo = 4
-    s3.Cout = 64
-    assert hip_lib.dsm_conv3d_s3_fwd(ctypes.byref(s3), null) == -2        # Cout = 32 only
     # ABI v6: precision / x_amax of the split kernels, dsm_absmax
     a.x, a.precision = 16, 7
     assert hip_lib.dsm_conv3d_fwd(ctypes.byref(a), null) == -1            # unknown precision

@@ -215,9 +215,9 @@ def test_config5_psmnet_train_step_540x960_four_pairs(hip_lib):
     """BASELINE config #5 at its real per-GPU shape: ``train.train_step`` on PSMNet, 540x960,
     D=192, 4 pairs on one GPU (the share of batch 32 over 8 GPUs; the gradient all-reduce of
     the other 7 is covered by the world-size-2 gloo tests).  fp32, as the reference computes
-    (stackhourglass.py:124) -- see DESIGN.md on config #5's "fp16".  Checks: the volume
-    convolution (4,64,48,135,240) = 1.59 GB stays on the bf16x3 plan (just under the 2 GiB
-    limit of its 32-bit offsets), every parameter gets a finite gradient, the loss is finite
+    (stackhourglass.py:124); tests/test_train_f16_gpu.py runs the same step in the fp16 mode of
+    config #5.  Checks: the volume convolution (4,64,48,135,240) = 1.59 GB runs on the z-sliding
+    kernel (32-bit offsets per input plane), every parameter gets a finite gradient, the loss is finite
     and decreases over Adam steps on the same batch, peak memory is reported."""
     import ctypes
     from dsmnet_amd import _lib, costvolume as cv, train
@@ -228,7 +228,7 @@ def test_config5_psmnet_train_step_540x960_four_pairs(hip_lib):
     a.Do, a.Ho, a.Wo = 48, 135, 240
     a.stride, a.transposed, a.relu = 1, 0, 0
     a.x = a.w_packed = a.y = 16                       # the plan looks at shapes only
-    assert "bf16x3" in cv.conv3d_plan_name(a), cv.conv3d_plan_name(a)
+    assert "conv3d_zs_" in cv.conv3d_plan_name(a), cv.conv3d_plan_name(a)
     torch.manual_seed(0)
     model = model_create_by_name("psmnet", 192).cuda()
     for i in (1, 2, 3):
