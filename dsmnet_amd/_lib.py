@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdsmnet_hip.so")
+# DSM_LIB_PATH: another build of the same ABI (same-box A/B runs of kernel variants: scripts/ab_builds.sh)
+LIB_PATH = os.environ.get("DSM_LIB_PATH") or os.path.join(_HERE, "csrc", "libdsmnet_hip.so")
 
 c_int, c_void_p, c_size_t = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 

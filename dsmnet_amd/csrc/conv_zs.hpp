@@ -52,6 +52,15 @@ template <int PM> struct ZsCfg {
   static constexpr int NSTEP = 27;
   static constexpr int WSTEP = 2 * NPW * 1024;        // weight bytes per (tap position, z-tap) step
   static constexpr int CONV0 = NSTEP - NPF;           // first step that splits / stores a staged quad
+  // weight ring: fragments are requested WAHEAD steps before their use.  A step is 8 product groups =
+  // 48 (bf16x3) / 24 (f16x2) / 8 (f16) MFMAs of 16 cycles: two steps cover an L2 round trip in the
+  // six-MFMA form only.  The ring has 9 slots (9 divides NSTEP: slot = step % 9 stays consistent
+  // across chunks); only WAHEAD + 1 of them are live at a time.
+#ifndef DSM_ZS_WAHEAD
+#define DSM_ZS_WAHEAD (PM == 3 ? 2 : 4)
+#endif
+  static constexpr int WRING = 9, WAHEAD = DSM_ZS_WAHEAD;
+  static_assert(NSTEP % WRING == 0 && WAHEAD < WRING, "weight ring");
   static_assert(32 * NPF <= NVP && NVP % 16 == 0, "image row");
 };
 
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
   using C = ZsCfg<PM>;
   using frag = typename Prec<PM>::frag;
   constexpr int NP = C::NP, NPW = C::NPW, TY = C::TY, IX = C::IX, NV = C::NV, NPF = C::NPF, ROW = C::ROW,
-                IMG = C::IMG, NSTEP = C::NSTEP, WSTEP = C::WSTEP, CONV0 = C::CONV0;
+                IMG = C::IMG, NSTEP = C::NSTEP, WSTEP = C::WSTEP, CONV0 = C::CONV0, WRING = C::WRING, WAHEAD = C::WAHEAD;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
 
   f32x4 acc[3][4][2];
   frag xq[2][4][NP];            // [tap-position parity][row][plane]
-  frag wq[3][2][NP];            // [step % 3][a][plane]
+  frag wq[WRING][2][NP];        // [step % WRING][a][plane]
   f32x4 pf[NPF];
 
   auto zero_set = [&](auto sc_) {
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int q = 0; q < NP; ++q)
-        wq[s % 3][a][q] = __builtin_bit_cast(
+        wq[s % WRING][a][q] = __builtin_bit_cast(
             frag, buffer_load16(wrsrc, lane16, wb + s * WSTEP + (a * NPW + q) * 1024));
   };
   auto xload = [&](auto tpc, auto rc, const unsigned char* rd) {
@@ -262,8 +271,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
   }
   static_for<0, 3>([&](auto s) { zero_set(s); });
   const unsigned w0 = (unsigned)cur.cg * (NSTEP * WSTEP);
-  wload(std::integral_constant<int, 0>{}, w0);
-  wload(std::integral_constant<int, 1>{}, w0);
+  static_for<0, WAHEAD>([&](auto sc_) { wload(sc_, w0); });
   int img = 0;
 
   while (true) {
@@ -289,8 +297,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
       constexpr int s = decltype(sc_)::value;
       constexpr int tp = s / 3, kz = s % 3;
       // unconditional part of the step: weight ring, next tap position's fragments, staging
-      if constexpr (s + 2 < NSTEP) wload(std::integral_constant<int, s + 2>{}, wcur);
-      else wload(std::integral_constant<int, s + 2 - NSTEP>{}, wnext);
+      if constexpr (s + WAHEAD < NSTEP) wload(std::integral_constant<int, s + WAHEAD>{}, wcur);
+      else wload(std::integral_constant<int, s + WAHEAD - NSTEP>{}, wnext);
       if constexpr (tp + 1 < 9) {
         if constexpr (kz == 0) {
           xload(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, 0>{}, rd);
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int a = 0; a < 2; ++a) mma16<PM>(acc[set][r][a], wq[s % 3][a], xq[tp & 1][r]);
+          for (int a = 0; a < 2; ++a) mma16<PM>(acc[set][r][a], wq[s % WRING][a], xq[tp & 1][r]);
       }
       // the operand split of one staged quad of the next chunk, in this step's issue gaps
       if constexpr (s >= CONV0) convert(std::integral_constant<int, s - CONV0>{}, wr);
