@@ -28,7 +28,8 @@ class Bn3dArgs(ctypes.Structure):
                 ("affine", c_void_p), ("workspace", c_void_p), ("gout", c_void_p), ("dy", c_void_p),
                 ("dresidual", c_void_p), ("B", c_int), ("C", c_int),
                 ("Dy", c_int), ("Hy", c_int), ("Wy", c_int), ("Dr", c_int), ("Hr", c_int), ("Wr", c_int),
-                ("relu", c_int), ("momentum", ctypes.c_float), ("eps", ctypes.c_float)]
+                ("relu", c_int), ("momentum", ctypes.c_float), ("eps", ctypes.c_float),
+                ("out_amax", c_void_p), ("dy_amax", c_void_p), ("dres_amax", c_void_p)]
 
 
 class Conv3dArgs(ctypes.Structure):
@@ -61,8 +62,8 @@ SIGNATURES = {
     "dsm_absmax": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "dsm_conv3d_fwd": (c_int, [ctypes.POINTER(Conv3dArgs), c_void_p]),
     "dsm_conv3d_plan": (c_int, [ctypes.POINTER(Conv3dArgs), ctypes.c_char_p, c_int]),
-    "dsm_conv3d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p]),
-    "dsm_conv2d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 10 + [c_void_p]),
+    "dsm_conv3d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_void_p] * 3),
+    "dsm_conv2d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p] * 3),
     "dsm_conv3d_cout1_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "dsm_deconv3d_cout1_bwd": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "dsm_bn3d_train_fwd": (c_int, [ctypes.POINTER(Bn3dArgs), c_void_p]),

@@ -738,17 +738,26 @@ def spp_head(raw, skip, w_t, scale, shift):
 # ----------------------------------------------------------------------------
 # Conv3d / ConvTranspose3d (k=3) with autograd: training through the 3-D trunk
 # ----------------------------------------------------------------------------
+def _wgrad_precision(x, g):
+    """(precision, x_amax, g_amax) of a weight-gradient launch under the current ``conv_precision``."""
+    mode = _OPTIONS["conv_precision"]
+    if mode not in ("f16x2", "f16"):
+        return _lib.DSM_PREC_F32, None, None
+    return (_lib.DSM_PREC_F16X2 if mode == "f16x2" else _lib.DSM_PREC_F16), amax_of(x), amax_of(g)
+
+
 def _wgrad(x_cl, g_cl, cx, cg, stride):
     """dW[g][c][tap] = sum_v X[v*stride + tap - 1][c] G[v][g]  ->  (cg, cx, 3, 3, 3)."""
     B = x_cl.shape[0]
     ws = torch.empty((cx // 32) * (cg // 32) * 27 * 1024, device=x_cl.device, dtype=torch.float32)
     dw = torch.empty((cg, cx, 3, 3, 3), device=x_cl.device, dtype=torch.float32)
-    with torch.cuda.device(x_cl.device), _timed("conv3d_wgrad_kernel<S=%d,%dx%d>" % (stride, cx, cg), 54.0 * cx * cg * B *
-                                                g_cl.shape[2] * g_cl.shape[3] * g_cl.shape[4]):
+    prec, xa, ga = _wgrad_precision(x_cl, g_cl)
+    with torch.cuda.device(x_cl.device), _timed("conv3d_wgrad_%s_kernel<S=%d,%dx%d>" % (_OPTIONS["conv_precision"], stride, cx, cg),
+                                                54.0 * cx * cg * B * g_cl.shape[2] * g_cl.shape[3] * g_cl.shape[4]):
         rc = _lib.load().dsm_conv3d_wgrad(_p(x_cl), _p(g_cl), _p(ws), _p(dw), B, cx, cg,
                                           x_cl.shape[2], x_cl.shape[3], x_cl.shape[4],
                                           g_cl.shape[2], g_cl.shape[3], g_cl.shape[4], stride,
-                                          _conv_flags(), _stream())
+                                          _conv_flags(), prec, _p(xa), _p(ga), _stream())
     _lib.check(rc, "dsm_conv3d_wgrad")
     return dw
 
@@ -762,7 +771,7 @@ class Conv3dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, transposed):
         _require_device("Conv3dFunction", x, weight, bias)
-        x = to_channels_last_3d(x)
+        x = carry_amax(to_channels_last_3d(x), x)
         cout = weight.shape[1] if transposed else weight.shape[0]
         packed = pack_conv3d_weight(weight, transposed)
         shift = None if bias is None else bias.detach().contiguous()
@@ -776,7 +785,9 @@ class Conv3dFunction(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         stride, transposed, has_bias = ctx.cfg
-        gy = to_channels_last_3d(gy)
+        gy = carry_amax(to_channels_last_3d(gy), gy)
+        if needs_amax():
+            amax_of(x), amax_of(gy)             # one pass each at most, shared by bwd-data and bwd-weight
         B, cin = x.shape[0], x.shape[1]
         cout = gy.shape[1]
         dx = dw = db = None
@@ -868,12 +879,19 @@ class BnAddRelu3dFunction(torch.autograd.Function):
         a.running_mean = None if running_mean is None else running_mean.data_ptr()
         a.running_var = None if running_var is None else running_var.data_ptr()
         a.relu, a.momentum, a.eps = int(relu), float(momentum), float(eps)
+        oa = None
+        if needs_amax():                               # the next convolution's x_amax, from this epilogue
+            oa = _ARENA.slot(y.device)
+            a.out_amax = oa.data_ptr()
         with torch.cuda.device(y.device), _timed("bn3d_train_fwd_kernels", 4.0 * (2 * y.numel() + out.numel())):
             rc = _lib.load().dsm_bn3d_train_fwd(ctypes.byref(a), _stream())
         _lib.check(rc, "dsm_bn3d_train_fwd")
         ctx.save_for_backward(y, out if relu == 1 else None, affine)
         ctx.cfg = (int(relu), None if residual is None else tuple(residual.shape), gamma is not None,
                    beta is not None)
+        if oa is not None:
+            out._dsm_amax = oa
+            ctx.out_amax = oa
         return out
 
     @staticmethod
@@ -897,6 +915,12 @@ class BnAddRelu3dFunction(torch.autograd.Function):
         a.y, a.affine, a.workspace = y.data_ptr(), affine.data_ptr(), ws.data_ptr()
         a.out = None if out is None else out.data_ptr()
         a.gout, a.dy, a.relu = gout.data_ptr(), dy.data_ptr(), relu
+        if needs_amax():                               # the maxima of the gradients this node hands on
+            dy._dsm_amax = _ARENA.slot(y.device)
+            a.dy_amax = dy._dsm_amax.data_ptr()
+            if dres is not None:
+                dres._dsm_amax = _ARENA.slot(y.device)
+                a.dres_amax = dres._dsm_amax.data_ptr()
         with torch.cuda.device(y.device), _timed("bn3d_train_bwd_kernels", 4.0 * (3 * y.numel() + gout.numel())):
             rc = _lib.load().dsm_bn3d_train_bwd(ctypes.byref(a), _stream())
         _lib.check(rc, "dsm_bn3d_train_bwd")
@@ -947,9 +971,11 @@ def _wgrad2d(x_cl, g_cl, stride, dilation):
     _, cg, Hg, Wg = g_cl.shape
     ws = torch.empty((cx // 32) * (cg // 32) * 9 * 1024, device=x_cl.device, dtype=torch.float32)
     dw = torch.empty((cg, cx, 3, 3), device=x_cl.device, dtype=torch.float32)
+    prec, xa, ga = _wgrad_precision(x_cl, g_cl)
     with torch.cuda.device(x_cl.device), _timed("conv2d_wgrad_kernel", 18.0 * cx * cg * B * Hg * Wg):
         rc = _lib.load().dsm_conv2d_wgrad(_p(x_cl), _p(g_cl), _p(ws), _p(dw), B, cx, cg, Hx, Wx,
-                                          Hg, Wg, int(stride), int(dilation), _conv_flags(), _stream())
+                                          Hg, Wg, int(stride), int(dilation), _conv_flags(), prec,
+                                          _p(xa), _p(ga), _stream())
     _lib.check(rc, "dsm_conv2d_wgrad")
     return dw
 

@@ -83,15 +83,32 @@ __device__ __forceinline__ int quad_of(long i, int nq) {
   return (nq & (nq - 1)) == 0 ? (int)(i & (nq - 1)) : (int)(i % nq);
 }
 
+// max |v| of a launch's output for the fp16 convolution modes (include/dsmnet_hip.h: x_amax): a wave
+// reduction, then one atomic per wave -- and none once the slot holds as much (the blocks of an
+// element-wise pass are many; most of them find the maximum already there)
+__device__ __forceinline__ float amax4(float am, const f32x4 v) {
+  return fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+// (the apply kernels walk their elements with a bounded grid, so a launch issues at most a few
+// thousand of these: same-address atomics serialise in L2 at ~5 ns each)
+__device__ __forceinline__ void wave_amax(float* slot, float am) {
+  if (!slot) return;
+#pragma unroll
+  for (int o = 32; o; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+  if ((threadIdx.x & 63) == 0 && am > *reinterpret_cast<volatile float*>(slot))
+    atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, am));
+}
+constexpr int BN_APPLY_MAX_BLOCKS = 4096;
+
 // out[b,z,y,x,:] = relu?( y*scale + shift (+ res) ) over the common corner; thread = (out voxel, quad)
 // relu: 0 none, 1 after the addition (PSMNet), 2 before it (GCNet)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ res,
                                                        const float* __restrict__ aff, float* __restrict__ out,
-                                                       BnDims d, int relu) {
+                                                       BnDims d, int relu, float* __restrict__ out_amax) {
   const int nq = d.C >> 2;
   const long n = (long)d.B * d.Do * d.Ho * d.Wo * nq;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  float am = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
   const int q = quad_of(i, nq);
   long vy, vr;
   if (same_boxes(d, res != nullptr)) {            // no crop: one linear index for y, res and out
@@ -111,6 +128,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   if (res) t += *reinterpret_cast<const f32x4*>(res + vr * d.C + 4 * q);
   if (relu == 1) t = relu4(t);
   *reinterpret_cast<f32x4*>(out + i * 4) = t;
+  am = amax4(am, t);
+  }
+  wave_amax(out_amax, am);
 }
 
 // g' = g masked by the ReLU; per channel sum g' and sum g'*xhat over the output corner
@@ -161,12 +181,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ out,
                                                            const float* __restrict__ g, const float* __restrict__ aff,
                                                            const double* __restrict__ sums, float* __restrict__ dy,
-                                                           float* __restrict__ dres, BnDims d, int relu, double n) {
+                                                           float* __restrict__ dres, BnDims d, int relu, double n,
+                                                           float* __restrict__ dy_amax, float* __restrict__ dres_amax) {
   const int nq = d.C >> 2;
   const int Dm = max(d.Dy, d.Dr), Hm = max(d.Hy, d.Hr), Wm = max(d.Wy, d.Wr);
   const long total = (long)d.B * Dm * Hm * Wm * nq;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
+  float amy = 0.f, amr = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
   const int q = quad_of(i, nq);
   const bool flat = same_boxes(d, dres != nullptr || d.Dr > 0);
   bool in_o = true, in_y = true, in_r = dres != nullptr;
@@ -201,12 +222,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < 4; ++k) { mg[k] = (float)(sums[4 * q + k] / n); mgx[k] = (float)(sums[d.C + 4 * q + k] / n); }
     const f32x4 xhat = (yv - mean) * istd;
-    *reinterpret_cast<f32x4*>(dy + vy * d.C + 4 * q) = sc * (gv - mg - xhat * mgx);
+    const f32x4 dyv = sc * (gv - mg - xhat * mgx);
+    *reinterpret_cast<f32x4*>(dy + vy * d.C + 4 * q) = dyv;
+    amy = amax4(amy, dyv);
   }
   if (in_r) {
     const long vr = vr_;
-    *reinterpret_cast<f32x4*>(dres + vr * d.C + 4 * q) = relu == 2 ? graw : gv;
+    const f32x4 drv = relu == 2 ? graw : gv;
+    *reinterpret_cast<f32x4*>(dres + vr * d.C + 4 * q) = drv;
+    amr = amax4(amr, drv);
   }
+  }
+  wave_amax(dy_amax, amy);
+  wave_amax(dres_amax, amr);
 }
 
 int check_bn(const dsm_bn3d_args* a) {
@@ -253,8 +281,10 @@ extern "C" int dsm_bn3d_train_fwd(const dsm_bn3d_args* a, dsm_stream_t stream) {
                      (double)nvox, a->momentum, a->eps);
   const long n = (long)d.B * d.Do * d.Ho * d.Wo * (d.C / 4);
   DSM_REQUIRE(n / 256 < 0x7fffffffL, DSM_ERR_UNSUPPORTED);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s, (const float*)a->y,
-                     (const float*)a->residual, (const float*)a->affine, (float*)a->out, d, a->relu);
+  // a bounded grid when a maximum is asked for (one atomic per wave at most)
+  const long ablocks = dsm_cdiv(n, 256);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)(a->out_amax && ablocks > BN_APPLY_MAX_BLOCKS ? BN_APPLY_MAX_BLOCKS : ablocks)), dim3(256), 0, s, (const float*)a->y,
+                     (const float*)a->residual, (const float*)a->affine, (float*)a->out, d, a->relu, a->out_amax);
   return dsm_launch_status();
 }
 
@@ -277,8 +307,10 @@ extern "C" int dsm_bn3d_train_bwd(const dsm_bn3d_args* a, dsm_stream_t stream) {
   const long total = (long)d.B * Dm * Hm * Wm * (d.C / 4);
   DSM_REQUIRE(total / 256 < 0x7fffffffL, DSM_ERR_UNSUPPORTED);
   const double n = (double)a->B * a->Dy * a->Hy * a->Wy;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(dsm_cdiv(total, 256)), dim3(256), 0, s, (const float*)a->y,
+  const long bblocks = dsm_cdiv(total, 256);
+  const bool want_max = a->dy_amax || a->dres_amax;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)(want_max && bblocks > BN_APPLY_MAX_BLOCKS ? BN_APPLY_MAX_BLOCKS : bblocks)), dim3(256), 0, s, (const float*)a->y,
                      (const float*)a->out, (const float*)a->gout, (const float*)a->affine, (const double*)sums,
-                     (float*)a->dy, (float*)a->dresidual, d, a->relu, n);
+                     (float*)a->dy, (float*)a->dresidual, d, a->relu, n, a->dy_amax, a->dres_amax);
   return dsm_launch_status();
 }

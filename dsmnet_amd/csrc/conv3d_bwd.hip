@@ -36,6 +36,7 @@ struct WgradParams {
   int Dx, Hx, Wx;                                  // X volume
   int Dg, Hg, Wg;                                  // G volume (the strided side)
   int ntx, nty, ntiles, npair;
+  const float* x_amax; const float* g_amax;        // fp16 modes: absolute maxima of X and G (device scalars)
 };
 
 // S: stride of X relative to G.  Tile: 1 z x TY rows x 32 columns of G voxels.
@@ -147,53 +148,121 @@ typedef short ws16x4 __attribute__((ext_vector_type(4)));
 typedef short ws16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned wu32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void wsplit4(const f32x4 v, wu32x2 (&pl)[3]) {
-  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  float r[4] = {v.x, v.y, v.z, v.w};
+typedef _Float16 wf16x8 __attribute__((ext_vector_type(8)));
+
+// precision modes as in conv_split.hpp: PM = 3 bf16x3 (six MFMAs per product), PM = 2 f16x2 (the
+// power-of-two-scaled operand as two fp16 terms, three MFMAs), PM = 1 f16 (one MFMA)
+template <int PM> struct WPrec;
+template <> struct WPrec<3> { static constexpr int NP = 3; typedef wbf16x8 frag; };
+template <> struct WPrec<2> { static constexpr int NP = 2; typedef wf16x8 frag; };
+template <> struct WPrec<1> { static constexpr int NP = 1; typedef wf16x8 frag; };
+
+__device__ __forceinline__ int w_amax_exponent(float amax) {      // conv_common.hpp: dsm_amax_exponent
+  const int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
+  const int e = 12 - ex;
+  return e < -60 ? -60 : (e > 60 ? 60 : e);
+}
+__device__ __forceinline__ float w_pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+
+// four fp32 values -> their NP planes (two dwords per plane); `sx`: the tensor's power-of-two scale (PM < 3)
+template <int PM>
+__device__ __forceinline__ void wsplit4(const f32x4 v, float sx, wu32x2 (&pl)[WPrec<PM>::NP]) {
+  if constexpr (PM == 3) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    float r[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    unsigned u[2];
+    for (int k = 0; k < 3; ++k) {
+      unsigned u[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f2 t = {r[2 * i], r[2 * i + 1]};
+        u[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, b2));
+        if (k < 2) {
+          r[2 * i] -= __builtin_bit_cast(float, u[i] << 16);
+          r[2 * i + 1] -= __builtin_bit_cast(float, u[i] & 0xffff0000u);
+        }
+      }
+      pl[k] = wu32x2{u[0], u[1]};
+    }
+  } else {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const float r[4] = {v.x, v.y, v.z, v.w};
+    unsigned hi[2], lo[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const f2 t = {r[2 * i], r[2 * i + 1]};
-      u[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, b2));
-      if (k < 2) {
-        r[2 * i] -= __builtin_bit_cast(float, u[i] << 16);
-        r[2 * i + 1] -= __builtin_bit_cast(float, u[i] & 0xffff0000u);
+      asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi[i]) : "v"(r[2 * i]), "s"(sx));
+      asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi[i]) : "v"(r[2 * i + 1]), "s"(sx));
+      if constexpr (PM == 2) {
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(r[2 * i]), "s"(sx), "v"(hi[i]));
+        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(r[2 * i + 1]), "s"(sx), "v"(hi[i]));
+        const f2 t = {r0, r1};
+        lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, h2));
       }
     }
-    pl[k] = wu32x2{u[0], u[1]};
+    pl[0] = wu32x2{hi[0], hi[1]};
+    if constexpr (PM == 2) pl[1] = wu32x2{lo[0], lo[1]};
+  }
+}
+
+template <int PM>
+__device__ __forceinline__ void wmma(f32x16& c, const typename WPrec<PM>::frag (&x)[WPrec<PM>::NP],
+                                     const typename WPrec<PM>::frag (&g)[WPrec<PM>::NP]) {
+  if constexpr (PM == 3) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], g[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], g[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], g[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], g[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], g[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], g[0], c, 0, 0, 0);
+  } else if constexpr (PM == 2) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[1], g[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], g[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], g[0], c, 0, 0, 0);
+  } else {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], g[0], c, 0, 0, 0);
   }
 }
 
 // eight voxels (rows row0 .. row0 + 7*RS, RS rows apart) of this lane's channel: two transposed reads
-template <int RS>
-__device__ __forceinline__ wbf16x8 tr_frag(const unsigned char* lane_base, int byte_off) {
+template <int RS, typename FR>
+__device__ __forceinline__ FR tr_frag(const unsigned char* lane_base, int byte_off) {
   typedef __attribute__((address_space(3))) ws16x4 lds_s16x4;
   const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lane_base + byte_off));
   const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lane_base + byte_off + 4 * RS * 64));
   const ws16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(wbf16x8, v);
+  return __builtin_bit_cast(FR, v);
 }
 
-template <int S, int TY, int KZ, int DIL>
+template <int S, int TY, int KZ, int DIL, int NP = 3>
 struct WgradGeo {
   static constexpr int IY = (TY - 1) * S + 2 * DIL + 1, IX = 31 * S + 2 * DIL + 1, IZ = KZ;
   static constexpr int NXV = IZ * IY * IX, NGV = TY * 32;          // voxels of the X halo tile / G tile
   static constexpr int XPL = NXV * 64, GPL = NGV * 64;             // plane strides, bytes
   static constexpr int NTAP = 9 * KZ, NACC = KZ == 3 ? 7 : 9;
-  static constexpr size_t LDS = 3 * (size_t)(XPL + GPL);
+  static constexpr size_t TILES = NP * (size_t)(XPL + GPL), FOLD = KZ == 1 ? 4 * 4 * 16 * 64 * 4 : 0;
+  static constexpr size_t LDS = TILES > FOLD ? TILES : FOLD;     // KZ = 1 folds the four waves' sums through LDS
 };
 
-template <int S, int TY, int KZ, int DIL>
-__global__ __launch_bounds__(NT_, 1) void wgrad_bf16x3_kernel(WgradParams p) {
-  using G = WgradGeo<S, TY, KZ, DIL>;
+template <int PM, int S, int TY, int KZ, int DIL>
+__global__ __launch_bounds__(NT_, 1) void wgrad_split_kernel(WgradParams p) {
+  constexpr int NP = WPrec<PM>::NP;
+  using frag = typename WPrec<PM>::frag;
+  using G = WgradGeo<S, TY, KZ, DIL, NP>;
   constexpr int IY = G::IY, IX = G::IX, NXV = G::NXV, NGV = G::NGV, XPL = G::XPL, GPL = G::GPL;
   constexpr int NTAP = G::NTAP, NACC = G::NACC;
   extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
-  unsigned char* const xt = wl;                    // [plane][voxel (z, y, x)][32 ch] bf16
-  unsigned char* const gt = wl + 3 * XPL;          // [plane][voxel (y, x)][32 ch] bf16
+  unsigned char* const xt = wl;                    // [plane][voxel (z, y, x)][32 ch] 16-bit
+  unsigned char* const gt = wl + NP * XPL;         // [plane][voxel (y, x)][32 ch] 16-bit
+  float sxs = 1.f, sgs = 1.f, so = 1.f;            // operand scales and the output factor (PM < 3)
+  if constexpr (PM != 3) {
+    const int ex = w_amax_exponent(*p.x_amax), eg = w_amax_exponent(*p.g_amax);
+    sxs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w_pow2f(ex))));
+    sgs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w_pow2f(eg))));
+    so = w_pow2f(-(ex + eg));
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int pair = blockIdx.y;
@@ -247,10 +316,10 @@ __global__ __launch_bounds__(NT_, 1) void wgrad_bf16x3_kernel(WgradParams p) {
     for (int i = 0; i < NXR; ++i) {
       const int e = tid + i * NT_;
       if (e < PE) {
-        wu32x2 pl[3];
-        wsplit4(src[i], pl);
+        wu32x2 pl[NP];
+        wsplit4<PM>(src[i], sxs, pl);
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < NP; ++k)
           *reinterpret_cast<wu32x2*>(xt + k * XPL + (slot * (IY * IX) + (e >> 3)) * 64 + (e & 7) * 8) = pl[k];
       }
     }
@@ -273,10 +342,10 @@ __global__ __launch_bounds__(NT_, 1) void wgrad_bf16x3_kernel(WgradParams p) {
     for (int i = 0; i < NGR; ++i) {
       const int e = tid + i * NT_;
       if (e < NGV * 8) {
-        wu32x2 pl[3];
-        wsplit4(src[i], pl);
+        wu32x2 pl[NP];
+        wsplit4<PM>(src[i], sgs, pl);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) *reinterpret_cast<wu32x2*>(gt + k * GPL + (e >> 3) * 64 + (e & 7) * 8) = pl[k];
+        for (int k = 0; k < NP; ++k) *reinterpret_cast<wu32x2*>(gt + k * GPL + (e >> 3) * 64 + (e & 7) * 8) = pl[k];
       }
     }
   };
@@ -328,14 +397,14 @@ __global__ __launch_bounds__(NT_, 1) void wgrad_bf16x3_kernel(WgradParams p) {
     constexpr int NKB = TY * 2;
     const int kb0 = KZ == 3 ? 0 : wave * (NKB / 4), kb1 = KZ == 3 ? NKB : kb0 + NKB / 4;
     auto xoff_of = [&](int kb) { return (((kb >> 1) * S) * IX + 16 * (kb & 1) * S) * 64; };
-    wbf16x8 xf[2][3], gf[2][3];
-    auto read_x = [&](wbf16x8 (&d)[3], int o) __attribute__((always_inline)) {
+    frag xf[2][NP], gf[2][NP];
+    auto read_x = [&](frag (&d)[NP], int o) __attribute__((always_inline)) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) d[k] = tr_frag<S>(xlane, o + k * XPL);
+      for (int k = 0; k < NP; ++k) d[k] = tr_frag<S, frag>(xlane, o + k * XPL);
     };
-    auto read_g = [&](wbf16x8 (&d)[3], int kb) __attribute__((always_inline)) {
+    auto read_g = [&](frag (&d)[NP], int kb) __attribute__((always_inline)) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) d[k] = tr_frag<1>(glane, kb * 1024 + k * GPL);
+      for (int k = 0; k < NP; ++k) d[k] = tr_frag<1, frag>(glane, kb * 1024 + k * GPL);
     };
     read_g(gf[0], kb0);
     read_x(xf[0], xoff_of(kb0) + xtap[0]);
@@ -357,16 +426,7 @@ __global__ __launch_bounds__(NT_, 1) void wgrad_bf16x3_kernel(WgradParams p) {
             read_x(xf[xp ^ 1], xoffn + xtap[0]);
           }
           __builtin_amdgcn_sched_barrier(0);         // the next step's reads stay ahead of these MFMAs
-          const wbf16x8 xh = xf[xp][0], xm = xf[xp][1], xlo = xf[xp][2];
-          const wbf16x8 gh = gf[par][0], gm = gf[par][1], glo = gf[par][2];
-          f32x16 c = acc[a];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, gm, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xlo, gh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, glo, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, gh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, gm, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, gh, c, 0, 0, 0);
-          acc[a] = c;
+          wmma<PM>(acc[a], xf[xp], gf[par]);
           __builtin_amdgcn_sched_barrier(0);
         });
       });
@@ -398,7 +458,7 @@ __global__ __launch_bounds__(NT_, 1) void wgrad_bf16x3_kernel(WgradParams p) {
 #pragma unroll
           for (int w = 0; w < 4; ++w) v += fold[((w * 4 + wave) * 16 + i) * 64 + lane];
           const int c = (i & 3) + 8 * (i >> 2) + 4 * h;
-          atomicAdd(dst + c * 32, v);
+          atomicAdd(dst + c * 32, v * so);
         }
       }
     });
@@ -413,7 +473,7 @@ __global__ __launch_bounds__(NT_, 1) void wgrad_bf16x3_kernel(WgradParams p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int c = (i & 3) + 8 * (i >> 2) + 4 * h;
-        atomicAdd(dst + c * 32, acc[a][i]);
+        atomicAdd(dst + c * 32, acc[a][i] * so);
       }
     }
   });
@@ -432,9 +492,9 @@ __global__ void wgrad_permute_kernel(const float* __restrict__ ws, float* __rest
   dw[i] = ws[(((long)pair * ntap + tap) * 32 + (c & 31)) * 32 + (g & 31)];
 }
 
-template <int S, int TY, int KZ, int DIL>
-int launch_wgrad_bf16x3(WgradParams p, float* dw, hipStream_t s) {
-  using G = WgradGeo<S, TY, KZ, DIL>;
+template <int PM, int S, int TY, int KZ, int DIL>
+int launch_wgrad_split(WgradParams p, float* dw, hipStream_t s) {
+  using G = WgradGeo<S, TY, KZ, DIL, WPrec<PM>::NP>;
   static_assert(G::LDS <= 160 * 1024, "LDS");
   static_assert(KZ == 3 || (TY * 2) % 4 == 0, "KZ = 1 splits the k-blocks over the four waves");
   const size_t wsbytes = (size_t)p.npair * G::NTAP * 32 * 32 * sizeof(float);
@@ -447,12 +507,12 @@ int launch_wgrad_bf16x3(WgradParams p, float* dw, hipStream_t s) {
   if (bx > p.ntiles) bx = p.ntiles;
   static thread_local bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute((const void*)wgrad_bf16x3_kernel<S, TY, KZ, DIL>,
+    if (hipFuncSetAttribute((const void*)wgrad_split_kernel<PM, S, TY, KZ, DIL>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS) != hipSuccess)
       return DSM_ERR_LAUNCH;
     configured = true;
   }
-  hipLaunchKernelGGL((wgrad_bf16x3_kernel<S, TY, KZ, DIL>), dim3(bx, p.npair), dim3(NT_), G::LDS, s, p);
+  hipLaunchKernelGGL((wgrad_split_kernel<PM, S, TY, KZ, DIL>), dim3(bx, p.npair), dim3(NT_), G::LDS, s, p);
   const long n = (long)p.Cx * p.Cg * G::NTAP;
   hipLaunchKernelGGL(wgrad_permute_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s,
                      (const float*)p.ws, dw, p.Cx, p.Cg, G::NTAP);
@@ -759,8 +819,11 @@ __global__ __launch_bounds__(256) void deconv_cout1_bwd_weight_kernel(
 // ws: workspace of (Cx/32)*(Cg/32)*27*32*32 floats (zeroed here); dw: (Cg, Cx, 27), overwritten.
 extern "C" int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, int Cx,
                                 int Cg, int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int stride,
-                                int flags, dsm_stream_t stream) {
+                                int flags, int precision, const float* x_amax, const float* g_amax,
+                                dsm_stream_t stream) {
   DSM_REQUIRE(x && g && ws && dw, DSM_ERR_ARG);
+  DSM_REQUIRE(precision == DSM_PREC_F32 || ((precision == DSM_PREC_F16 || precision == DSM_PREC_F16X2) &&
+                                            ((flags & DSM_CONV_FP32_MFMA) || (x_amax && g_amax))), DSM_ERR_ARG);
   DSM_REQUIRE(B > 0 && Cx > 0 && Cg > 0 && Dx > 0 && Hx > 0 && Wx > 0 && Dg > 0 && Hg > 0 && Wg > 0,
               DSM_ERR_ARG);
   DSM_REQUIRE(stride == 1 || stride == 2, DSM_ERR_UNSUPPORTED);
@@ -772,9 +835,15 @@ extern "C" int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw
   p.x = (const float*)x; p.g = (const float*)g; p.ws = (float*)ws;
   p.B = B; p.Cx = Cx; p.Cg = Cg; p.Dx = Dx; p.Hx = Hx; p.Wx = Wx; p.Dg = Dg; p.Hg = Hg; p.Wg = Wg;
   p.npair = (Cx / 32) * (Cg / 32);
-  if (!(flags & DSM_CONV_FP32_MFMA)) {             // fp32 on the bf16 pipe (bf16x3)
-    if (stride == 1) return launch_wgrad_bf16x3<1, 4, 3, 1>(p, (float*)dw, s);
-    return launch_wgrad_bf16x3<2, 1, 3, 1>(p, (float*)dw, s);
+  p.x_amax = x_amax; p.g_amax = g_amax;
+  if (!(flags & DSM_CONV_FP32_MFMA)) {             // fp32 operands on the 16-bit matrix pipe
+#define DSM_WG3(PM_) \
+    if (stride == 1) return launch_wgrad_split<PM_, 1, 4, 3, 1>(p, (float*)dw, s); \
+    return launch_wgrad_split<PM_, 2, 1, 3, 1>(p, (float*)dw, s)
+    if (precision == DSM_PREC_F16X2) { DSM_WG3(2); }
+    if (precision == DSM_PREC_F16) { DSM_WG3(1); }
+    DSM_WG3(3);
+#undef DSM_WG3
   }
   if (stride == 1) return launch_wgrad<1, 4, 3, 1>(p, (float*)dw, s);
   return launch_wgrad<2, 2, 3, 1>(p, (float*)dw, s);
@@ -784,8 +853,11 @@ extern "C" int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw
 // g: (B,Hg,Wg,Cg); ws: (Cx/32)*(Cg/32)*9*32*32 floats; dw: (Cg, Cx, 3, 3), overwritten.
 extern "C" int dsm_conv2d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, int Cx,
                                 int Cg, int Hx, int Wx, int Hg, int Wg, int stride, int dilation,
-                                int flags, dsm_stream_t stream) {
+                                int flags, int precision, const float* x_amax, const float* g_amax,
+                                dsm_stream_t stream) {
   DSM_REQUIRE(x && g && ws && dw, DSM_ERR_ARG);
+  DSM_REQUIRE(precision == DSM_PREC_F32 || ((precision == DSM_PREC_F16 || precision == DSM_PREC_F16X2) &&
+                                            ((flags & DSM_CONV_FP32_MFMA) || (x_amax && g_amax))), DSM_ERR_ARG);
   DSM_REQUIRE(B > 0 && Cx > 0 && Cg > 0 && Hx > 0 && Wx > 0 && Hg > 0 && Wg > 0, DSM_ERR_ARG);
   DSM_REQUIRE((stride == 1 && (dilation == 1 || dilation == 2)) || (stride == 2 && dilation == 1),
               DSM_ERR_UNSUPPORTED);
@@ -797,10 +869,16 @@ extern "C" int dsm_conv2d_wgrad(const void* x, const void* g, void* ws, void* dw
   p.x = (const float*)x; p.g = (const float*)g; p.ws = (float*)ws;
   p.B = B; p.Cx = Cx; p.Cg = Cg; p.Dx = 1; p.Hx = Hx; p.Wx = Wx; p.Dg = 1; p.Hg = Hg; p.Wg = Wg;
   p.npair = (Cx / 32) * (Cg / 32);
+  p.x_amax = x_amax; p.g_amax = g_amax;
   if (!(flags & DSM_CONV_FP32_MFMA)) {
-    if (stride == 2) return launch_wgrad_bf16x3<2, 4, 1, 1>(p, (float*)dw, s);
-    if (dilation == 2) return launch_wgrad_bf16x3<1, 8, 1, 2>(p, (float*)dw, s);
-    return launch_wgrad_bf16x3<1, 8, 1, 1>(p, (float*)dw, s);
+#define DSM_WG2(PM_) \
+    if (stride == 2) return launch_wgrad_split<PM_, 2, 4, 1, 1>(p, (float*)dw, s); \
+    if (dilation == 2) return launch_wgrad_split<PM_, 1, 8, 1, 2>(p, (float*)dw, s); \
+    return launch_wgrad_split<PM_, 1, 8, 1, 1>(p, (float*)dw, s)
+    if (precision == DSM_PREC_F16X2) { DSM_WG2(2); }
+    if (precision == DSM_PREC_F16) { DSM_WG2(1); }
+    DSM_WG2(3);
+#undef DSM_WG2
   }
   if (stride == 2) return launch_wgrad<2, 4, 1, 1>(p, (float*)dw, s);
   if (dilation == 2) return launch_wgrad<1, 8, 1, 2>(p, (float*)dw, s);

@@ -107,6 +107,11 @@ class GraphedTrainStep(object):
         torch.cuda.synchronize()
 
     def _step(self):
+        from . import costvolume as cv
+        with cv.amax_scope(self.batch.device):      # fp16 convolution modes: one arena of maxima per step
+            return self._step_body()
+
+    def _step_body(self):
         b = self.batch
         self.optim.zero_grad(set_to_none=True)
         scales, disps = self.model(b[:, :3], b[:, 3:6])

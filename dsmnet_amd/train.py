@@ -165,6 +165,12 @@ def train_step(model, optim, lossfun, batch, world=None):
     gradients -- on a rank without ground truth), so the collective calls always match; the
     number of ranks that had ground truth rides in the same bucket and the optimizer step is
     skipped on all ranks together when it is zero."""
+    from . import costvolume as cv
+    with cv.amax_scope(batch.device):            # fp16 convolution modes: one arena of maxima per step
+        return _train_step(model, optim, lossfun, batch, world)
+
+
+def _train_step(model, optim, lossfun, batch, world):
     model.train()
     world = _world(world)
     imL, imR, dispL = _split(batch)

@@ -228,12 +228,14 @@ int dsm_conv3d_plan(const dsm_conv3d_args* args, char* buf, int len);
  * ws: scratch of (Cx/32)*(Cg/32)*27*1024 floats; dw: Cg*Cx*27 floats, overwritten.
  * Channels must be multiples of 32.  Sums are accumulated with fp32 atomics (order varies).
  * flags (ABI v5): DSM_CONV_FP32_MFMA keeps the exact fp32-input MFMA kernel; 0 = fp32 operands on
- * the bf16 pipe (bf16x3, as the forward kernels), staged once as [voxel][channel] bf16 planes and
- * read through gfx950's transposed LDS read.
+ * the 16-bit matrix pipe, staged once as [voxel][channel] 16-bit planes and read through gfx950's
+ * transposed LDS read.  precision (ABI v6, DSM_PREC_*): bf16x3 (DSM_PREC_F32), or the fp16 forms
+ * f16x2 / f16, which scale X and G by powers of two taken from the device scalars x_amax / g_amax
+ * (max |X|, max |G|; required then -- dsm_absmax or a producer's y_amax).
  * ------------------------------------------------------------------------- */
 int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, int Cx, int Cg,
                      int Dx, int Hx, int Wx, int Dg, int Hg, int Wg, int stride, int flags,
-                     dsm_stream_t stream);
+                     int precision, const float* x_amax, const float* g_amax, dsm_stream_t stream);
 
 /* (ABI v5) The same for the 2-D towers' 3x3 layers -- autograd through convbn / BasicBlock
  * (models/psmnet/submodule.py:10-13,24-46) when the feature extraction trains.  padding = dilation;
@@ -241,7 +243,7 @@ int dsm_conv3d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, in
  * ws: (Cx/32)*(Cg/32)*9*32*32 floats (zeroed here); dw: (Cg, Cx, 3, 3) torch layout, overwritten. */
 int dsm_conv2d_wgrad(const void* x, const void* g, void* ws, void* dw, int B, int Cx, int Cg,
                      int Hx, int Wx, int Hg, int Wg, int stride, int dilation, int flags,
-                     dsm_stream_t stream);
+                     int precision, const float* x_amax, const float* g_amax, dsm_stream_t stream);
 
 /* Cout = 1, stride 1 (classifier heads): g (B,D,H,W); x (B,D,H,W,C); w_packed [27][C];
  * dx (B,D,H,W,C) or NULL; dw_tapmajor [27][C] or NULL (the caller transposes to (1,C,27)). */
@@ -288,6 +290,12 @@ typedef struct dsm_bn3d_args {
   int Dr, Hr, Wr;
   int relu;
   float momentum, eps;
+  /* ABI v6, optional (the fp16 convolution modes' x_amax): max |out| (fwd), max |dy| and
+   * max |dresidual| (bwd) are folded into these device floats with an atomic maximum on the float
+   * bits; the caller zeroes them first. */
+  float*       out_amax;
+  float*       dy_amax;
+  float*       dres_amax;
 } dsm_bn3d_args;
 int dsm_bn3d_train_fwd(const dsm_bn3d_args* args, dsm_stream_t stream);
 int dsm_bn3d_train_bwd(const dsm_bn3d_args* args, dsm_stream_t stream);

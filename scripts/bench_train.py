@@ -1,4 +1,4 @@
-"""Timing of a PSMNet training step (BASELINE config #5 in fp32, one MI355X): train-mode forward,
+"""Timing of a PSMNet training step (BASELINE config #5; DSM_CONV_PRECISION=f16x2|f16|bf16x3|fp32; one MI355X): train-mode forward,
 smooth-L1 on the three heads, backward, SGD step.  Prints ms/step and the per-kernel breakdown
 of the HIP launches (forward, bwd-data and bwd-weight kernels)."""
 import sys
@@ -27,11 +27,12 @@ opt = torch.optim.SGD([q for q in m.parameters() if q.requires_grad], lr=1e-4)
 
 
 def step():
-    opt.zero_grad(set_to_none=True)
-    _, preds = m(left, right)
-    loss = sum(w * F.smooth_l1_loss(p, target) for w, p in zip((0.5, 0.7, 1.0), preds))
-    loss.backward()
-    opt.step()
+    with cv.amax_scope(left.device):
+        opt.zero_grad(set_to_none=True)
+        _, preds = m(left, right)
+        loss = sum(w * F.smooth_l1_loss(p, target) for w, p in zip((0.5, 0.7, 1.0), preds))
+        loss.backward()
+        opt.step()
     return loss
 
 
@@ -49,8 +50,8 @@ b.record()
 torch.cuda.synchronize()
 cv.set_timer(None)
 ms = a.elapsed_time(b) / N
-print("PSMNet training step %dx%d batch %d D=192 fp32: %.1f ms/step (%.2f pairs/s), loss %.4f"
-      % (H, W, B, ms, B * 1e3 / ms, loss.item()))
+print("PSMNet training step %dx%d batch %d D=192, conv_precision %s: %.1f ms/step (%.2f pairs/s), loss %.4f"
+      % (H, W, B, cv.get_option("conv_precision"), ms, B * 1e3 / ms, loss.item()))
 tot = 0.0
 for k, v in sorted(timer.summary().items(), key=lambda kv: -kv[1]["ms"]):
     n = v["launches"]

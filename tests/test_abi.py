@@ -60,13 +60,14 @@ def test_argument_validation_returns_codes(hip_lib):
     assert hip_lib.dsm_conv_packed_weight_bytes(128, 128, 1, 3) == 128 * 128 * 9 * (4 + 6 + 4) + 16
     assert hip_lib.dsm_conv_packed_weight_bytes(128, 32, 1, 1) == 128 * 32 * 4
     # ABI v5: weight gradients (flags argument), the 2-D entry point
-    assert hip_lib.dsm_conv3d_wgrad(null, one, one, one, 1, 32, 32, 4, 4, 4, 4, 4, 4, 1, 0, null) == -1
-    assert hip_lib.dsm_conv3d_wgrad(one, one, one, one, 1, 32, 48, 4, 4, 4, 4, 4, 4, 1, 0, null) == -2   # Cg % 32
-    assert hip_lib.dsm_conv3d_wgrad(one, one, one, one, 1, 32, 32, 4, 4, 4, 4, 4, 4, 3, 0, null) == -2   # stride
-    assert hip_lib.dsm_conv2d_wgrad(one, one, one, null, 1, 32, 32, 8, 8, 8, 8, 1, 1, 0, null) == -1
-    assert hip_lib.dsm_conv2d_wgrad(one, one, one, one, 1, 32, 32, 8, 8, 4, 4, 2, 2, 0, null) == -2      # stride 2 + dilation 2
-    assert hip_lib.dsm_conv2d_wgrad(one, one, one, one, 1, 24, 32, 8, 8, 8, 8, 1, 1, 0, null) == -2      # Cx % 32
-    assert hip_lib.dsm_conv2d_wgrad(ctypes.c_void_p(20), one, one, one, 1, 32, 32, 8, 8, 8, 8, 1, 1, 0, null) == -4
+    assert hip_lib.dsm_conv3d_wgrad(null, one, one, one, 1, 32, 32, 4, 4, 4, 4, 4, 4, 1, 0, 0, null, null, null) == -1
+    assert hip_lib.dsm_conv3d_wgrad(one, one, one, one, 1, 32, 48, 4, 4, 4, 4, 4, 4, 1, 0, 0, null, null, null) == -2   # Cg % 32
+    assert hip_lib.dsm_conv3d_wgrad(one, one, one, one, 1, 32, 32, 4, 4, 4, 4, 4, 4, 3, 0, 0, null, null, null) == -2   # stride
+    assert hip_lib.dsm_conv3d_wgrad(one, one, one, one, 1, 32, 32, 4, 4, 4, 4, 4, 4, 1, 0, _lib.DSM_PREC_F16, null, null, null) == -1   # fp16 modes need both maxima
+    assert hip_lib.dsm_conv2d_wgrad(one, one, one, null, 1, 32, 32, 8, 8, 8, 8, 1, 1, 0, 0, null, null, null) == -1
+    assert hip_lib.dsm_conv2d_wgrad(one, one, one, one, 1, 32, 32, 8, 8, 4, 4, 2, 2, 0, 0, null, null, null) == -2      # stride 2 + dilation 2
+    assert hip_lib.dsm_conv2d_wgrad(one, one, one, one, 1, 24, 32, 8, 8, 8, 8, 1, 1, 0, 0, null, null, null) == -2      # Cx % 32
+    assert hip_lib.dsm_conv2d_wgrad(ctypes.c_void_p(20), one, one, one, 1, 32, 32, 8, 8, 8, 8, 1, 1, 0, 0, null, null, null) == -4
     # ABI v6: precision / x_amax of the split kernels, dsm_absmax
     a.x, a.precision = 16, 7
     assert hip_lib.dsm_conv3d_fwd(ctypes.byref(a), null) == -1            # unknown precision
