@@ -106,6 +106,163 @@ __global__ __launch_bounds__(256) void corr1d_fwd_kernel(
   }
 }
 
+// ----------------------------------------------------------------------------
+// The tile kernel (r03): stride 1 | 2, W % 4 == 0, D <= 4 DB NDH.
+// Workgroup = (b, y, 64 x), 4 NDH waves: wave = (channel quarter cw, d half dh).  What the r01 kernel
+// above does in four stage -> barrier -> compute -> barrier rounds with <1 wave per SIMD (40 us for
+// 36.5 MB that fit the Infinity Cache) happens here without a barrier before the reduction:
+//  * only the fR window [x0 - 4 DB NDH S, x0 + 64) goes through LDS (57 KB at C = 128, D <= 48: two
+//    workgroups per CU, the whole 384x1280 problem resident at once); every wave stages the rows of
+//    ITS OWN channels -- all its 16-byte loads in flight together, no workgroup barrier -- and reads
+//    them back wave-locally;
+//  * the fL quad of a lane's four columns comes straight from global memory (the four d-group lanes of
+//    a column share the address), a four-deep register ring ahead of its use;
+//  * lane = (xg 0..15, dg 0..3) owns a 4(x) x DB(d) register block: per channel (4 + DB S)/4
+//    ds_read_b128 feed 4 DB FMAs (DB = 12: 48 FMAs, packed by the compiler into 24 v_pk_fma_f32, per
+//    4 reads); every lane of every wave is busy (41 planes padded to 48);
+//  * the channel quarters' partial sums meet in LDS (the window's space, dead by then) and each wave
+//    writes its share of the d planes.
+// ----------------------------------------------------------------------------
+template <int S, int DB, int NDH>
+__global__ __launch_bounds__(256 * NDH, (NDH == 1 ? 2 : 1)) void corr1d_tile_kernel(
+    const float* __restrict__ fL, const float* __restrict__ fR, float* __restrict__ out,
+    int C, int H, int W, int D) {
+  constexpr int DP = 4 * DB * NDH, PADL = DP * S, RW = TX + PADL;
+  constexpr int QR = RW / 4;                    // staged quads per channel
+  constexpr int WIN = 4 + DB * S;               // floats of the fR window per thread
+  static_assert((DB * S) % 4 == 0, "16-byte aligned window reads");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const Rs = lds;                        // [C][RW]; column j <-> x = x0 - PADL + j
+  const int x0 = blockIdx.x * TX, y = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cw = wave & 3, dh = wave >> 2;      // channel quarter, d half
+  const int xg = lane & 15, dg = lane >> 4, d0 = (dh * 4 + dg) * DB;
+  const long plane = (long)H * W;
+  const float* const baseL = fL + (long)b * C * plane + (long)y * W;
+  const float* const baseR = fR + (long)b * C * plane + (long)y * W;
+  const int cq = (C + 3) / 4, c_lo = cw * cq, c_hi = min(C, c_lo + cq);
+
+  float acc[DB][4];
+#pragma unroll
+  for (int i = 0; i < DB; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
+  const int x = x0 + 4 * xg;
+  const bool live = x < W;
+  // branch-free channel walk (the host sends only C % 16 == 0 here: every quarter is whole groups of
+  // four channels): a lane past the row's end reads the last quad of the row (its sums are never
+  // stored); pointers advance by uniform increments, LDS reads take immediate offsets
+  const float* lptr = baseL + (live ? x : W - 4) + (long)c_lo * plane;
+  const float* rcur = Rs + 4 * xg + PADL - (d0 + DB) * S + c_lo * RW;      // 16-B aligned
+  constexpr int LA = 4;                         // fL quads in flight ahead of their use
+  const int nc = c_hi - c_lo;
+  f32x4 lq[LA];
+  // channels [c_from, c_to) of the quarter, groups of four
+  auto compute = [&](int c_from, int c_to) __attribute__((always_inline)) {
+    f32x4 wq[2][WIN / 4];                       // the window of the channel in hand and of the next one
+#pragma unroll
+    for (int k = 0; k < WIN / 4; ++k) wq[0][k] = *reinterpret_cast<const f32x4*>(rcur + 4 * k);
+    for (int c4 = c_from; c4 < c_to; c4 += LA) {
+      // the next group's fL quads (the last group re-reads itself: nothing past the tensor is touched)
+      const float* lnext = lptr + (c4 + LA < nc ? (long)LA * plane : 0l);
+#pragma unroll
+      for (int u = 0; u < LA; ++u) {
+        const f32x4 l = lq[u];
+        lq[u] = *reinterpret_cast<const f32x4*>(lnext + (long)u * plane);
+#pragma unroll
+        for (int k = 0; k < WIN / 4; ++k)       // (the row past the last staged one: read, never used)
+          wq[(u + 1) & 1][k] = *reinterpret_cast<const f32x4*>(rcur + (u + 1) * RW + 4 * k);
+        float win[WIN];
+#pragma unroll
+        for (int k = 0; k < WIN / 4; ++k) {
+          const f32x4 r = wq[u & 1][k];
+          win[4 * k] = r.x; win[4 * k + 1] = r.y; win[4 * k + 2] = r.z; win[4 * k + 3] = r.w;
+        }
+#pragma unroll
+        for (int i = 0; i < DB; ++i) {
+          // output x = x0 + 4 xg + j pairs with fR column x - (d0 + i) S = window[j + (DB - i) S]
+          acc[i][0] = fmaf(l.x, win[0 + (DB - i) * S], acc[i][0]);
+          acc[i][1] = fmaf(l.y, win[1 + (DB - i) * S], acc[i][1]);
+          acc[i][2] = fmaf(l.z, win[2 + (DB - i) * S], acc[i][2]);
+          acc[i][3] = fmaf(l.w, win[3 + (DB - i) * S], acc[i][3]);
+        }
+      }
+      lptr = lnext;
+      rcur += LA * RW;
+    }
+  };
+
+  // ---- stage the fR rows of this wave's channels (the d halves of a quarter split them) and compute
+  // the channels that have arrived while the later loads are still in flight: the whole problem is
+  // resident at once, so a load-everything-then-compute kernel would leave the memory system idle
+  // while the chip multiplies and the ALUs idle while it loads
+  {
+    const int n = nc * QR;                      // quads of the quarter
+    constexpr int NB = S == 1 ? 16 : 8;         // loads in flight per thread and batch (registers: S = 2 has the wider window)
+#pragma unroll
+    for (int u = 0; u < LA; ++u) lq[u] = *reinterpret_cast<const f32x4*>(lptr + (long)u * plane);
+    int done = 0;                               // channels of the quarter multiplied so far
+    for (int i0 = dh * 64 + lane; i0 - (dh * 64 + lane) < n; i0 += 64 * NDH * NB) {
+      f32x4 v[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int i = i0 + 64 * NDH * u;
+        const int c = i / QR, k = i - c * QR;
+        const int xr = x0 - PADL + 4 * k;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < n && xr >= 0 && xr < W)         // W % 4 == 0 and xr % 4 == 0: a quad is all in or all out
+          v[u] = *reinterpret_cast<const f32x4*>(baseR + (c_lo + c) * plane + xr);
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < NB; g4 += 4) {
+#pragma unroll
+        for (int u = g4; u < g4 + 4; ++u) {
+          const int i = i0 + 64 * NDH * u;
+          if (i < n) {
+            const int c = i / QR, k = i - c * QR;
+            *reinterpret_cast<f32x4*>(Rs + (c_lo + c) * RW + 4 * k) = v[u];
+          }
+        }
+        if constexpr (NDH == 1) {
+          // wave-private rows: LDS serves one wave's operations in order -- no workgroup barrier
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          // quads [0, first quad of the next store group) of the quarter are in LDS now
+          const int upto = min(n, (i0 - lane) + 64 * (g4 + 4));
+          const int ready = min(nc, (upto / QR) & ~(LA - 1));
+          if (ready > done) { compute(done, ready); done = ready; }
+        }
+      }
+    }
+    if constexpr (NDH == 2) {
+      __syncthreads();                          // the two d halves of a quarter staged it together
+      compute(0, nc);
+    } else if (done < nc) {
+      compute(done, nc);
+    }
+  }
+
+  // ---- the channel quarters' partial sums meet in LDS: P[cw][d][x]; then every wave finishes its share
+  __syncthreads();                              // the window is dead
+  constexpr int PW = TX + 4;                    // row pitch (floats)
+  float* const P = lds;                         // [4][DP][PW]
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+    *reinterpret_cast<f32x4*>(P + (cw * DP + d0 + i) * PW + 4 * xg) =
+        f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+  __syncthreads();
+  if (!live) return;
+  // wave (cw, dh) finishes planes (dh 4 + cw) DB + {dg, dg + 4, ...}: the four dg lanes of a column
+  // step through the group together
+#pragma unroll
+  for (int t = 0; t < DB / 4; ++t) {
+    const int d = (dh * 4 + cw) * DB + dg + 4 * t;
+    if (d >= D) continue;
+    f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s4 += *reinterpret_cast<const f32x4*>(P + (w * DP + d) * PW + 4 * xg);
+    *reinterpret_cast<f32x4*>(out + (((long)b * D + d) * H + y) * W + x) = s4;
+  }
+}
+
 // Any stride: one thread per output element (kept for strides other than 1, 2).
 __global__ __launch_bounds__(256) void corr1d_fwd_generic_kernel(
     const float* __restrict__ fL, const float* __restrict__ fR, float* __restrict__ out,
@@ -144,6 +301,31 @@ __global__ __launch_bounds__(256) void box_filter_kernel(
     }
   }
   dst[(long)blockIdx.z * H * W + (long)y * W + x] = a / (float)(k * k);
+}
+
+// The same for k = 3 on rows of W % 4 == 0: a thread owns four outputs of one (plane, row) and reads
+// the three source rows as one 16-byte load + the two neighbours each (the source -- a correlation
+// volume just written -- is cache-resident; the scalar kernel above spent 39 us on 20 MB).
+__global__ __launch_bounds__(256) void box3_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                   long nplanes, int H, int W) {
+  const int wq = W >> 2;
+  const long n = nplanes * H * wq;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int xq = (int)(i % wq);
+  const long row = i / wq;
+  const int y = (int)(row % H);
+  const float* p = src + row * W + 4 * xq;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    if (y + dy < 0 || y + dy >= H) continue;
+    const float* q = p + (long)dy * W;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(q);
+    const float l = xq > 0 ? q[-1] : 0.f, r = xq + 1 < wq ? q[4] : 0.f;
+    a += f32x4{l + v.x + v.y, v.x + v.y + v.z, v.y + v.z + v.w, v.z + v.w + r};
+  }
+  *reinterpret_cast<f32x4*>(dst + row * W + 4 * xq) = a * (1.f / 9.f);
 }
 
 // Backward:
@@ -193,7 +375,33 @@ extern "C" int dsm_corr1d_fwd(const void* fL, const void* fR, void* out, void* t
   float* raw = (float*)(ksize > 1 ? tmp : out);
   const int ndg = (D + DB - 1) / DB;
   const int vec = (W % 4 == 0) && dsm_aligned16(fL) && dsm_aligned16(fR) && dsm_aligned16(raw);
-  if ((stride == 1 || stride == 2) && ndg * 16 <= 256) {
+  // the tile kernel: the fR window of all channels in LDS at once; D <= 48 with four waves, D <= 96
+  // with eight (two d halves per channel quarter)
+  const int NDH_ = D <= 48 ? 1 : (D <= 96 ? 2 : 0);
+  const int DP_ = 48 * NDH_;
+  const size_t win_lds = (size_t)C * (TX + DP_ * stride) * sizeof(float);
+  const size_t red_lds = (size_t)4 * DP_ * (TX + 4) * sizeof(float);
+  const size_t tile_lds = win_lds > red_lds ? win_lds : red_lds;
+  if (vec && NDH_ && C % 16 == 0 && (stride == 1 || stride == 2) && tile_lds + 4096 <= 150 * 1024) {
+    dim3 grid(dsm_cdiv(W, TX), H, B);
+#define DSM_CORR_TILE(S_, NDH__)                                                                     \
+    do {                                                                                             \
+      static thread_local bool configured = false;                                                  \
+      if (!configured) {                                                                             \
+        if (hipFuncSetAttribute((const void*)corr1d_tile_kernel<S_, 12, NDH__>,                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) \
+          return DSM_ERR_LAUNCH;                                                                     \
+        configured = true;                                                                           \
+      }                                                                                              \
+      hipLaunchKernelGGL((corr1d_tile_kernel<S_, 12, NDH__>), grid, dim3(256 * NDH__), tile_lds + 4096, s, /* + a row of slack */ \
+                         (const float*)fL, (const float*)fR, raw, C, H, W, D);                       \
+    } while (0)
+    if (stride == 1 && NDH_ == 1) DSM_CORR_TILE(1, 1);
+    else if (stride == 1) DSM_CORR_TILE(1, 2);
+    else if (NDH_ == 1) DSM_CORR_TILE(2, 1);
+    else DSM_CORR_TILE(2, 2);
+#undef DSM_CORR_TILE
+  } else if ((stride == 1 || stride == 2) && ndg * 16 <= 256) {
     const int threads = ((ndg * 16 + 63) / 64) * 64;
     const size_t lds = (size_t)CC * (TX + TX + ndg * DB * stride) * sizeof(float);
     dim3 grid(dsm_cdiv(W, TX), H, B);
@@ -208,7 +416,11 @@ extern "C" int dsm_corr1d_fwd(const void* fL, const void* fR, void* out, void* t
     hipLaunchKernelGGL(corr1d_fwd_generic_kernel, grid, dim3(256), 0, s, (const float*)fL,
                        (const float*)fR, raw, C, H, W, D, stride);
   }
-  if (ksize > 1) {
+  if (ksize == 3 && vec && dsm_aligned16(out)) {
+    const long n = (long)B * D * H * (W / 4);
+    hipLaunchKernelGGL(box3_kernel, dim3(dsm_cdiv(n, 256)), dim3(256), 0, s, (const float*)raw, (float*)out,
+                       (long)B * D, H, W);
+  } else if (ksize > 1) {
     dim3 grid(dsm_cdiv(W, 256), H, B * D);
     hipLaunchKernelGGL(box_filter_kernel, grid, dim3(256), 0, s, (const float*)raw, (float*)out,
                        H, W, ksize);

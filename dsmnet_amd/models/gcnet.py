@@ -34,7 +34,7 @@ class feature2d(nn.Module):
             from ..blocks2d import _Folded2d, run_conv2d
             if not hasattr(self, "_fold"):
                 self._fold = _Folded2d()
-            return run_conv2d(self._fold, self.conv2, None, x).contiguous()   # NCHW for the volume build
+            return run_conv2d(self._fold, self.conv2, None, x)    # NHWC: what the virtual volume stages from
         return self.conv2(x)
 
 

@@ -2,7 +2,7 @@
 convolution shape.   python3 scripts/ab_conv2d_flags.py [cin cout H W B [D]]   (D > 1: a 3-D layer)"""
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 
 from dsmnet_amd import _lib, costvolume as cv

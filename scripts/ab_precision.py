@@ -3,7 +3,7 @@ precision mode, in one process: `python scripts/ab_precision.py [--modes bf16x3,
 HIP events around REP back-to-back launches of one layer (inputs resident, L2-warm weights)."""
 import argparse
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from dsmnet_amd import costvolume as cv, _lib
 

@@ -3,7 +3,7 @@
 import ctypes
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 
 from dsmnet_amd import _lib

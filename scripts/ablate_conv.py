@@ -2,7 +2,7 @@
 (DSM_ABLATE=N python dsmnet_amd/csrc/build.py --stamps; cp the .so to the path given).  Outputs
 of an ablated build are wrong on purpose; only the time matters."""
 import os, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from dsmnet_amd import _lib
 _lib.LIB_PATH = sys.argv[1]

@@ -1,7 +1,7 @@
 """Timing of the other BASELINE configs (parity cases, not the headline): DispNetC / iResNet
 correlation at 384x1280 and whole GCNet at 256x512, D=192, on one MI355X."""
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from dsmnet_amd import costvolume as cv
 from dsmnet_amd.models import model_create_by_name

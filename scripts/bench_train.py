@@ -2,7 +2,7 @@
 smooth-L1 on the three heads, backward, SGD step.  Prints ms/step and the per-kernel breakdown
 of the HIP launches (forward, bwd-data and bwd-weight kernels)."""
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
 from dsmnet_amd import costvolume as cv

@@ -1,7 +1,7 @@
 """Error of the convolution precisions against a float64 reference, per kernel variant and
 input magnitude, every precision in one process: `python scripts/precision_check.py`."""
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from dsmnet_amd import costvolume as cv
 for cin, cout, dims, xs in ((32, 32, (24, 48, 160), 3.0), (32, 32, (8, 16, 40), 1e-8), (32, 64, (8, 16, 40), 1e-8),

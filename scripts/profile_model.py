@@ -1,6 +1,6 @@
 """One model's eval forward, N times, for `rocprofv3 --kernel-trace --stats -- python3 scripts/profile_model.py <net> [H W] [N]`."""
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from dsmnet_amd.models import model_create_by_name
 net = sys.argv[1]

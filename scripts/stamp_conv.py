@@ -1,7 +1,7 @@
 """Diagnostic: where does a conv3d_mfma workgroup spend its cycles?  Uses the stamped build
 (python dsmnet_amd/csrc/build.py --stamps).  Prints per-phase cycle shares (wave 0 of each WG)."""
 import ctypes, os, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from dsmnet_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libdsmnet_hip_stamps.so")

@@ -1,7 +1,7 @@
 """Diagnostic: phase shares of the bf16x3 kernel on a small 2-D layer (stamped build:
 python dsmnet_amd/csrc/build.py --stamps)."""
 import ctypes, os, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from dsmnet_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libdsmnet_hip_stamps.so")
