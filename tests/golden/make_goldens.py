@@ -476,8 +476,8 @@ def gen_lr(store):
         me.D = D
         n, Fc, h, w = shp
         ns = {"torch": torch, "self": me, "fL": fL, "fR": fR, "n": n, "F": Fc, "h": h, "w": w}
-        if D > w:       # the reference's slices fL[:, :, :, :-i] misbehave for i >= w (empty vs
-            continue    # negative wrap); the legal range is D <= W, which is what is pinned
+        # D > W: for i >= w the reference's slices (`i:` / `:-i` on both sides) are all empty, so the
+        # planes past the width keep their zeros in the shifted half -- pinned as well
         exec(src, ns)
         tag = "volume_lr.D%d.%s" % (D, "x".join(map(str, shp)))
         check(tag + ".xL", ns["xL"], OO.concat_volume(fL, fR, D, False), 0.0)

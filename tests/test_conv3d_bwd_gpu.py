@@ -69,8 +69,16 @@ class _SignLog(object):
 
 def _trunk_step_errors(seed, hw=(16, 40), d4=8):
     """One train-mode trunk + heads step on a seeded input: relative max-abs error of every
-    checked gradient, and the number of ReLU inputs whose SIGN differs between the two
-    implementations (a unit within rounding distance of zero can take the other side)."""
+    checked gradient against the oracle's CPU autograd, and the number of ReLU inputs whose SIGN
+    differs between the two implementations.
+
+    The backward of a ReLU network is discontinuous: an activation within rounding distance of zero
+    can take the other side in the two implementations, and then the gradients legitimately differ
+    by what that unit carries.  The discontinuity is REMOVED here instead of budgeted for (ADVICE
+    r02): the product runs first and records the sign pattern of every ReLU input; the oracle's
+    trunk then runs with those masks forced (y = x * mask_k in place of its k-th F.relu -- the same
+    function wherever the signs agree, and the same derivative everywhere).  What is left is
+    arithmetic: summation order and the products' precision."""
     import torch.nn.functional as TF
     from dsmnet_amd import blocks3d
     from dsmnet_amd import costvolume as cv
@@ -79,28 +87,15 @@ def _trunk_step_errors(seed, hw=(16, 40), d4=8):
     OM.apply_head_scale("psmnet", sd, 0.05)
     fl, fr = seeded(seed, 1, 32, *hw), seeded(seed + 1, 1, 32, *hw)
     size = (4 * d4, 4 * hw[0], 4 * hw[1])
-    # oracle: leaves that require grad
-    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
-               else v.clone()) for k, v in sd.items()}
-    ofl, ofr = fl.clone().requires_grad_(True), fr.clone().requires_grad_(True)
-    n = OM.Net(osd, training=True)
-    olog, glog = _SignLog(), _SignLog()
-    orig = TF.relu
-    TF.relu = olog.wrap(orig)                      # the oracle's trunk calls F.relu
-    try:
-        costs = OM.psmnet_trunk(n, OO.concat_volume(ofl, ofr, d4, True))
-    finally:
-        TF.relu = orig
-    oloss = sum(OO.soft_argmin(c, size).mean() for c in costs)
     keys = ["dres0.0.0.weight", "dres0.0.1.weight", "dres1.2.0.weight", "dres2.conv1.0.0.weight",
             "dres2.conv5.0.weight", "dres3.conv6.0.weight", "dres4.conv2.1.bias",
             "classif1.2.weight", "classif3.0.0.weight"]
-    ogr = torch.autograd.grad(oloss, [osd[k] for k in keys] + [ofl, ofr])
-    # product
+    # product first: forward with the sign pattern of every ReLU input recorded
     m = model_create_by_name("psmnet", 192)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
     gfl, gfr = fl.cuda().requires_grad_(True), fr.cuda().requires_grad_(True)
+    glog = _SignLog()
     # the product's train-mode blocks are fused (BatchNorm + add + ReLU in one kernel): the sign
     # pattern of the ReLU's input is read off the block's output (out > 0 <=> input > 0)
     blocks3d._TRAIN_RELU_HOOK[0] = lambda out, mode: glog.masks.append((out.detach() > 0).cpu())
@@ -112,58 +107,76 @@ def _trunk_step_errors(seed, hw=(16, 40), d4=8):
         torch.relu = orig_t
         blocks3d._TRAIN_RELU_HOOK[0] = None
     loss = sum(cv.soft_argmin(c, size).mean() for c in gc)
+    assert len(glog.masks) == 21, len(glog.masks)
+    params = dict(m.named_parameters())
+    ggr = torch.autograd.grad(loss, [params[k] for k in keys] + [gfl, gfr])
+    # oracle: leaves that require grad; its k-th ReLU takes the product's k-th mask
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
+               else v.clone()) for k, v in sd.items()}
+    ofl, ofr = fl.clone().requires_grad_(True), fr.clone().requires_grad_(True)
+    n = OM.Net(osd, training=True)
+    state = {"k": 0, "flips": 0, "units": 0}
+
+    def forced_relu(x, *a, **k):
+        mask = glog.masks[state["k"]]
+        assert mask.shape == x.shape, (state["k"], mask.shape, x.shape)
+        state["k"] += 1
+        state["flips"] += int(((x.detach() > 0) != mask).sum())
+        state["units"] += mask.numel()
+        return x * mask.to(x.dtype)
+
+    orig = TF.relu
+    TF.relu = forced_relu                          # the oracle's trunk calls F.relu
+    try:
+        costs = OM.psmnet_trunk(n, OO.concat_volume(ofl, ofr, d4, True))
+    finally:
+        TF.relu = orig
+    assert state["k"] == 21
+    oloss = sum(OO.soft_argmin(c, size).mean() for c in costs)
+    ogr = torch.autograd.grad(oloss, [osd[k] for k in keys] + [ofl, ofr])
     assert abs(loss.item() - oloss.item()) <= 1e-3 * max(1.0, abs(oloss.item()))
     for a, b in zip(gc, costs):                                   # train-mode forward: tight
         assert maxerr(a, b) <= 2e-5 * b.abs().max().item()
-    assert len(olog.masks) == len(glog.masks) == 21, (len(olog.masks), len(glog.masks))
-    flips = units = 0
-    for a, b in zip(olog.masks, glog.masks):
-        assert a.shape == b.shape
-        flips += int((a != b).sum())
-        units += a.numel()
-    params = dict(m.named_parameters())
-    ggr = torch.autograd.grad(loss, [params[k] for k in keys] + [gfl, gfr])
     # running statistics were updated as nn.BatchNorm3d does
     assert maxerr(m.dres0[0][1].running_mean, osd["dres0.0.1.running_mean"]) <= 1e-4
     errs = {k: maxerr(g, r) / max(r.abs().max().item(), 1e-6)
             for k, g, r in zip(keys + ["fL", "fR"], ggr, ogr)}
-    return errs, flips, units
+    return errs, state["flips"], state["units"]
 
 
-def _check_against_flips(errs, flips, units, nvox_min):
-    """No flipped unit: every gradient within 2e-3 (measured 3e-6).  Each flipped unit may move
-    the gradients of a BatchNorm layer that sees ``nvox_min`` voxels per channel by ~1/nvox_min
-    (it changes one term of that channel's batch statistics); allow twice that per flip.
-    Rounding noise flips a ReLU input only when it lies within ~1e-6 of zero relative to the
-    layer's scale: at most a few per million units (measured 330 of 4.6e8 at the config #5 shape)."""
+GRAD_TOL = 1e-4      # relative to the largest entry of each gradient, same ReLU masks on both sides
+
+
+def _check_gradients(errs, flips, units):
+    """With the ReLU masks forced the gradients must agree to GRAD_TOL (measured ~3e-6: summation
+    order and the products' precision).  The flip count stays as a sanity line of its own: rounding
+    noise flips a ReLU input only when it lies within ~1e-6 of zero relative to the layer's scale --
+    at most a few per million units (measured 330 of 4.6e8 at the config #5 shape)."""
     worst = max(errs.values())
-    bound = 2e-3 + flips * 2.0 / nvox_min
-    assert flips <= 16 + 3e-6 * units, "too many sign flips (%d of %d) for rounding noise: %r" % (flips, units, errs)
-    assert worst <= bound, "flips=%d bound=%.3e: %r" % (flips, bound, errs)
+    print("gradients vs the mask-forced oracle: worst relative error %.2e; %d of %d ReLU inputs had "
+          "the other sign in the oracle's own forward" % (worst, flips, units))
+    assert worst <= GRAD_TOL, "worst %.3e (flips=%d): %r" % (worst, flips, errs)
+    assert flips <= 16 + 3e-6 * units, "too many sign flips (%d of %d) for rounding noise" % (flips, units)
 
 
 def test_psmnet_trunk_training_step_vs_oracle(hip_lib):
     """Train-mode forward + backward through the whole 3-D trunk and the three fused heads:
     parameter and input gradients against the oracle's CPU autograd, on three seeds.
 
-    The forward agrees to ~3e-6 on every input.  The backward of a ReLU network is discontinuous:
-    an activation within rounding distance of zero can take the other side in the two
-    implementations (about one seed in three, with the fp32-input MFMA as with the bf16x3
-    kernels).  The test therefore COUNTS those units (sign pattern of every ReLU input in both
-    implementations) and bounds each seed's error by what that many flips can explain; a seed
-    without flips must agree to 2e-3.  The smallest BN layer here sees 2x4x10 = 80 voxels."""
+    The forward agrees to ~3e-6 on every input; the oracle's backward runs with the product's ReLU
+    masks forced (see _trunk_step_errors), so every gradient must agree to GRAD_TOL on every seed."""
     for seed in (81, 71, 101):
         errs, flips, units = _trunk_step_errors(seed)
-        _check_against_flips(errs, flips, units, 80)
+        _check_gradients(errs, flips, units)
 
 
 def test_psmnet_trunk_training_step_at_config5_shape(hip_lib):
     """BASELINE config #5's own 1/4-resolution shape, one pair: features (1,32,135,240), D/4 = 48
     (540x960, D=192).  The odd sizes exercise the crop of ``myadd_3d`` on every level
     (135 -> 68 -> 34 -> 68 -> 136 vs 135; stackhourglass.py:10-20) in forward AND backward.
-    Gradients against the oracle's CPU autograd, bounded by the counted ReLU sign flips."""
+    Gradients against the oracle's CPU autograd with the product's ReLU masks forced: GRAD_TOL."""
     errs, flips, units = _trunk_step_errors(91, hw=(135, 240), d4=48)
-    _check_against_flips(errs, flips, units, 12 * 34 * 60)
+    _check_gradients(errs, flips, units)
 
 
 def test_psmnet_full_training_step(hip_lib):

@@ -91,16 +91,16 @@ def test_gcnet_end_to_end_64x128(hip_lib, golden_e2e):
 
 def test_dispnetcorr_end_to_end_256x512(hip_lib, golden_e2e):
     """DispNetC (BASELINE config #1 shape, on the GPU): HIP Corr1d inside the stock 2-D net;
-    all seven outputs.  Outputs are O(1) disparities; 2e-3 covers MIOpen-vs-oneDNN fp32
-    summation order through 26 layers."""
+    all seven outputs.  The north-star's 1e-3 px is asserted where it holds (the full-resolution
+    level of the pyramid; measured 6e-7 ... 1.5e-5), the measured error of every level is printed."""
     sd, cfg = golden_state(golden_e2e, "dispnetcorr")
     imL, imR = images(cfg["image_seed"], *cfg["hw"])
     m = load("dispnetcorr", sd)
     with torch.no_grad():
         scales, outs = m(imL.cuda(), imR.cuda())
     assert scales == list(range(7)) and len(outs) == 7
-    for i, o in enumerate(outs):
-        golden_e2e.compare("e2e.dispnetcorr.pr%d" % i, o, 2e-3)
+    errs = [golden_e2e.compare("e2e.dispnetcorr.pr%d" % i, o, DISP_TOL) for i, o in enumerate(outs)]
+    print("DispNetC e2e max |disp - golden| per level: " + " ".join("%.1e" % e for e in errs))
 
 
 def test_iresnet_end_to_end_256x512(hip_lib, golden_e2e):
@@ -112,8 +112,8 @@ def test_iresnet_end_to_end_256x512(hip_lib, golden_e2e):
         torch.manual_seed(cfg["torch_seed"])       # imwrap's random epsilon
         scales, outs = m(imL.cuda(), imR.cuda())
     assert len(outs) == 10 and scales[:3] == [0, 1, 2]
-    for i, o in enumerate(outs):
-        golden_e2e.compare("e2e.iresnet.out%d" % i, o, 2e-3)
+    errs = [golden_e2e.compare("e2e.iresnet.out%d" % i, o, DISP_TOL) for i, o in enumerate(outs)]
+    print("iResNet e2e max |disp - golden| per output: " + " ".join("%.1e" % e for e in errs))
 
 
 def test_psmnet_540x960_crop_add(hip_lib):
@@ -325,7 +325,7 @@ def test_gcnet_feature2d_runs_on_the_hip_kernels(hip_lib, golden_e2e):
     assert launches == 17, timer.summary().keys()
     with torch.no_grad():
         want = OM.gcnet_features(OM.Net(sd), imL)
-    assert got.shape == want.shape and got.is_contiguous()
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)   # NHWC: what the virtual volume stages from
     assert maxerr(got, want) <= 2e-5 * max(1.0, want.abs().max().item())
 
 

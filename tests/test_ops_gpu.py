@@ -225,6 +225,19 @@ def test_right_referenced_volume_vs_oracle(hip_lib, shape, D):
     assert torch.equal(got.cpu().contiguous(), OO.concat_volume_right(fL, fR, D))
 
 
+def test_right_referenced_volume_golden_cases(hip_lib):
+    """The same against the fixtures written from the reference's own lines (models/gcnet.py:155-164
+    executed by tests/golden/make_goldens.py), D > W included: bit-exact."""
+    from tests.conftest import Golden
+    from dsmnet_amd import costvolume as cv
+    g = Golden("lr")
+    assert any(c["D"] > c["shape"][3] for c in g.meta["volume_lr_cases"])
+    for case in g.meta["volume_lr_cases"]:
+        fL, fR = seeded(case["seed"], *case["shape"]), seeded(case["seed"] + 100, *case["shape"])
+        got = cv.concat_volume_right(fL.cuda(), fR.cuda(), case["D"])
+        g.compare(case["tag"] + ".xR", got, 0.0)
+
+
 def test_gcnet_lr_left_output_equals_gcnet(hip_lib, golden_e2e):
     """gcnet_LR(imL, imR)[0] is gcnet's output; its right output equals the left output of the
     mirrored problem only up to the trunk's (non-symmetric) weights, so it is checked against the
