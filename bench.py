@@ -258,10 +258,13 @@ def main():
     # measurement and the JSON line says so.
     rehearse = os.environ.get("DSM_BENCH_REHEARSE") == "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # no launcher around us: become one.  device_count() does not initialise the GPU.
-        ndev = torch.cuda.device_count()
-        if ndev < args.gpus and not rehearse:
-            raise SystemExit("--gpus %d: only %d GPU(s) visible" % (args.gpus, ndev))
+        # no launcher around us: become one.  The parent makes NO GPU call, not even a device count
+        # (torch falls back to hipGetDeviceCount -- hipInit -- when amdsmi discovery fails): a rank
+        # without a GPU of its own fails in the child, and that fails the run.  Under a profiler
+        # whose preloaded library has already initialised the GPU, starting children is refused.
+        if any("rocprofiler" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES")):
+            raise SystemExit("bench.py --gpus N cannot start its own ranks under a profiler preload: "
+                             "profile one rank (--gpus 1) or use torch.distributed.run")
         sys.exit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
@@ -287,12 +290,15 @@ def main():
 
     from dsmnet_amd import calibrate, costvolume
     from dsmnet_amd.models import model_create_by_name
+    t_start = time.perf_counter()
     torch.manual_seed(0)
     model = model_create_by_name("psmnet", MAXDISP).to(dev)
     left, right = synthetic_pair(1000 + rank, dev)          # every rank owns its own pair
     calibrate.calibrate_batchnorm(model, left, right)
     calibrate.calibrate_psmnet_heads(model, left, right)
     model.eval()
+    torch.cuda.synchronize()
+    startup_s = time.perf_counter() - t_start      # model build + BN / head calibration (no MIOpen solver search)
 
     def barrier():
         torch.cuda.synchronize()
@@ -406,6 +412,7 @@ def main():
                        "trunk_path": "z-sliding kernel for the 32-channel stride-1 layers, cost volume "
                                      "never materialised"},
             # rank 0's per-step GPU time from one HIP event per step inside the timed region
+            "startup_s": round(startup_s, 2),
             "step_ms": {"median": round(statistics.median(step_ms), 3), "min": round(min(step_ms), 3),
                         "max": round(max(step_ms), 3), "mean_wall": round(ms_per_step, 3)},
         }

@@ -33,6 +33,24 @@ _FUSED_TRAIN_2D_BN = _TRAIN_2D_MODE == "fused"
 _TRAIN_2D_MIN_PIXELS = int(__import__("os").environ.get("DSM_TRAIN_2D_MIN_PIXELS", 65536)) if _TRAIN_2D_MODE == "auto" else 0
 
 
+class own_kernels_only(object):
+    """``with own_kernels_only():`` every tower layer ``costvolume.Conv2dFunction`` covers runs on
+    it whatever its size (the ``auto`` threshold is lifted).  Used by ``calibrate.calibrate_batchnorm``:
+    a train-mode pass that never enters MIOpen's convolution solver search, whose first call per
+    shape costs tens of milliseconds to seconds -- times eight ranks starting on one host."""
+
+    def __enter__(self):
+        global _TRAIN_2D_MIN_PIXELS, _FUSED_TRAIN_2D
+        self.saved = (_TRAIN_2D_MIN_PIXELS, _FUSED_TRAIN_2D)
+        _TRAIN_2D_MIN_PIXELS, _FUSED_TRAIN_2D = 0, True
+        return self
+
+    def __exit__(self, *exc):
+        global _TRAIN_2D_MIN_PIXELS, _FUSED_TRAIN_2D
+        _TRAIN_2D_MIN_PIXELS, _FUSED_TRAIN_2D = self.saved
+        return False
+
+
 def fused_ok(conv, x):
     """Can ``conv`` (an nn.Conv2d) run on the MFMA kernel for input ``x``?"""
     if not (isinstance(conv, nn.Conv2d) and x.is_cuda and x.dtype == torch.float32):

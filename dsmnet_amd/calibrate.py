@@ -12,10 +12,13 @@ import torch
 
 
 def calibrate_batchnorm(model, left, right, passes=1):
-    """Train-mode forward passes (batch statistics; running stats updated), no autograd."""
+    """Train-mode forward passes (batch statistics; running stats updated), no autograd.  The
+    towers' convolutions run on this library's kernels whatever their size (no MIOpen solver
+    search at start-up: ``blocks2d.own_kernels_only``)."""
+    from .blocks2d import own_kernels_only
     was_training = model.training
     model.train()
-    with torch.no_grad():
+    with torch.no_grad(), own_kernels_only():
         for _ in range(passes):
             model(left, right)
     model.train(was_training)

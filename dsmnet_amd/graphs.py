@@ -60,7 +60,18 @@ class GraphedTrainStep(object):
     The optimizer must be built with ``capturable=True``; build it with ``fused=True`` as well: the
     capturable foreach Adam issues ~4 tiny kernels per parameter tensor (518 divisions and 145
     counter increments per PSMNet step, 3 ms of a 27 ms step at 256x512 -- DESIGN.md section 9).
-    Single process only (a captured gradient all-reduce is not wired up).
+
+    Several ranks (``torch.distributed`` initialised, or ``world=N``): the forward and the backward
+    are the captured graph -- the ~3,000 launches that would otherwise go through eight Python
+    interpreters sharing one host -- with every gradient a view of one flat buffer
+    (``sharding.FlatGradients``); after the replay come, eagerly, ONE all-reduce of that buffer
+    over RCCL (+ one division) and the fused optimizer step: three or four launches per step outside
+    the graph.  (Capturing the collective itself would save those at the price of tying the graph
+    to the communicator's state; with 20.9 MB per step and a step of >= 100 ms it buys nothing.)
+    A rank whose batch has no ground-truth pixel contributes zero gradients and takes part in the
+    collective all the same; the number of ranks that had ground truth rides in the same buffer
+    and the optimizer step is skipped on every rank together when it is zero (as
+    ``train.train_step`` does).
 
     An eager backward through the same model before the capture leaves gradient tensors and
     autograd buffers that were allocated OUTSIDE the capture's private pool, on the default
@@ -72,10 +83,15 @@ class GraphedTrainStep(object):
     starts from allocations of its own (tests/test_models_gpu.py:
     ``test_graphed_train_step_after_an_eager_step_on_the_same_model``)."""
 
-    def __init__(self, model, optim, lossfun, example_batch, warmup=3):
+    def __init__(self, model, optim, lossfun, example_batch, warmup=3, world=None, flat_gradients=None):
+        """``flat_gradients``: force (True) the multi-rank form -- forward + backward captured, flat
+        gradient exchange and optimizer step outside -- also in a single process (tests); default:
+        exactly when there are several ranks."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            raise NotImplementedError("GraphedTrainStep: single process only")
+        if world is None:
+            world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.world = int(world)
+        self.split = bool(flat_gradients) if flat_gradients is not None else self.world > 1
         if not example_batch.is_cuda or example_batch.shape[1] < 7:
             raise ValueError("GraphedTrainStep needs a CUDA (HIP) batch (B, >=7, H, W): imL | imR | dispL")
         if not all(g.get("capturable", False) for g in optim.param_groups):
@@ -84,7 +100,11 @@ class GraphedTrainStep(object):
         lossfun.capturable = True
         model.train()
         self.batch = example_batch[:, :7].clone()
+        self.flatgrads = None
         self._quiesce()
+        if self.split:
+            from . import sharding
+            self.flatgrads = sharding.FlatGradients(model.parameters(), n_extra=1)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -100,9 +120,12 @@ class GraphedTrainStep(object):
         """No gradient, no dead autograd graph, no kernel in flight: the state a capture (or the
         warm-up on the side stream) must start from."""
         import gc
-        self.optim.zero_grad(set_to_none=True)
-        for p in self.model.parameters():
-            p.grad = None
+        if self.flatgrads is None:
+            self.optim.zero_grad(set_to_none=True)
+            for p in self.model.parameters():
+                p.grad = None
+        else:
+            self.flatgrads.attach()
         gc.collect()
         torch.cuda.synchronize()
 
@@ -113,6 +136,16 @@ class GraphedTrainStep(object):
 
     def _step_body(self):
         b = self.batch
+        if self.flatgrads is not None:
+            # several ranks: only forward + backward are captured; gradients accumulate into the
+            # views of the flat buffer, whose last float counts "this rank had ground truth"
+            self.flatgrads.zero()
+            scales, disps = self.model(b[:, :3], b[:, 3:6])
+            loss = self.lossfun({"disp_gt": b[:, 6:7], "disps": disps, "scale_disps": scales,
+                                 "flag_smooth": True})
+            loss.backward()
+            self.flatgrads.extra.copy_((b[:, 6:7] > 0).any().to(self.flatgrads.flat.dtype).reshape(1))
+            return loss.detach(), [d.detach() for d in disps]
         self.optim.zero_grad(set_to_none=True)
         scales, disps = self.model(b[:, :3], b[:, 3:6])
         loss = self.lossfun({"disp_gt": b[:, 6:7], "disps": disps, "scale_disps": scales,
@@ -121,10 +154,18 @@ class GraphedTrainStep(object):
         self.optim.step()
         return loss.detach(), [d.detach() for d in disps]
 
+    def _exchange_and_update(self):
+        """The part of a multi-rank step that stays outside the graph."""
+        n_gt = self.flatgrads.allreduce(self.world)
+        if float(n_gt) > 0:                      # (a host read: one scalar per step)
+            self.optim.step()
+
     def __call__(self, batch):
         if batch.shape[0] != self.batch.shape[0] or batch.shape[2:] != self.batch.shape[2:]:
             raise ValueError("GraphedTrainStep was captured for %s, got %s"
                              % (tuple(self.batch.shape), tuple(batch.shape)))
         self.batch.copy_(batch[:, :7])
         self.graph.replay()
+        if self.flatgrads is not None:
+            self._exchange_and_update()
         return self.loss, self.disps

@@ -82,11 +82,13 @@ def allreduce_gradients(parameters, world=None, extra=None):
     if extra is not None:
         parts.append(extra.to(parts[0].dtype).reshape(-1))
     flat = torch.cat(parts)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    _all_reduce_sum(flat)
+    total = sum(p.numel() for p in params)
+    flat[:total].div_(world)                     # one launch; the trailing `extra` stays a sum
     off = 0
     for p in params:
         n = p.numel()
-        g = flat[off: off + n].view_as(p) / world
+        g = flat[off: off + n].view_as(p)
         if p.grad is None:
             p.grad = g.clone()
         else:
@@ -95,3 +97,57 @@ def allreduce_gradients(parameters, world=None, extra=None):
     if extra is None:
         return off
     return off, flat[off:].clone()
+
+
+def _all_reduce_sum(flat):
+    """dist.all_reduce(SUM); a CUDA tensor under the gloo backend (the rehearsal of the multi-rank
+    path on fewer GPUs than ranks) is staged through the host."""
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+
+class FlatGradients(object):
+    """The gradients of ``parameters`` as views of ONE flat buffer (plus ``n_extra`` trailing floats):
+    autograd accumulates into the views in place, so a step's gradient exchange is one memset
+    before the backward, one all-reduce and one division after it -- no concatenation, no copies
+    back, and nothing that changes an address between steps, which is what lets the backward live in
+    a captured hipGraph while the collective stays an ordinary RCCL call (``graphs.GraphedTrainStep``
+    with several ranks).  The reference has no counterpart (``stereo.py:34``, a commented-out
+    DistributedDataParallel)."""
+
+    def __init__(self, parameters, n_extra=0):
+        self.params = [p for p in parameters if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGradients: no parameter requires a gradient")
+        self.total = sum(p.numel() for p in self.params)
+        p0 = self.params[0]
+        self.flat = torch.zeros(self.total + n_extra, device=p0.device, dtype=p0.dtype)
+        self.attach()
+
+    def attach(self):
+        """(Re)bind every ``p.grad`` to its view of the flat buffer."""
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off: off + n].view_as(p)
+            off += n
+
+    @property
+    def extra(self):
+        return self.flat[self.total:]
+
+    def zero(self):
+        self.flat.zero_()
+
+    def allreduce(self, world=None):
+        """Sum over ranks, gradients divided by ``world``; ``extra`` comes back summed."""
+        if world is None:
+            world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world > 1:
+            _all_reduce_sum(self.flat)
+            self.flat[: self.total].div_(world)
+        return self.extra

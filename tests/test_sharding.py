@@ -49,9 +49,20 @@ def _worker(rank, world, port, q):
     n = sharding.allreduce_gradients(lin.parameters(), world)
     ok_grad = (n == 8 and torch.allclose(lin.weight.grad, torch.full((2, 3), 1.5))
                and torch.allclose(lin.bias.grad, torch.full((2,), 0.5)))
+    # the same through one flat buffer (graphs.GraphedTrainStep with several ranks): gradients are
+    # views of it, the trailing float comes back summed
+    lin2 = torch.nn.Linear(3, 2)
+    fg = sharding.FlatGradients(lin2.parameters(), n_extra=1)
+    fg.zero()
+    (lin2(torch.ones(1, 3)).sum() * (rank + 1)).backward()      # accumulates INTO the views
+    assert lin2.weight.grad.data_ptr() == fg.flat.data_ptr()
+    fg.extra.fill_(float(rank == 0))
+    n_gt = fg.allreduce(world)
+    ok_flat = (torch.allclose(lin2.weight.grad, torch.full((2, 3), 1.5)) and
+               torch.allclose(lin2.bias.grad, torch.full((2,), 1.5)) and float(n_gt) == 1.0)
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, ok_gather, ok_grad))
+    q.put((rank, ok_gather, ok_grad and ok_flat))
 
 
 def test_world_size_2_gloo():

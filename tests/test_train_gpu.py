@@ -100,3 +100,44 @@ def test_graphed_train_step_follows_the_eager_trajectory(hip_lib):
     assert graphed[-1] < graphed[0]
     with pytest.raises(ValueError):
         GraphedTrainStep(m2, torch.optim.Adam(m2.parameters(), lr=1e-4), lf2, batches[0])
+
+
+def test_graphed_train_step_in_its_multi_rank_form(hip_lib):
+    """The form a step takes with several ranks -- forward + backward captured, every gradient a view
+    of one flat buffer, the (here: one-rank, no-op) all-reduce and the fused optimizer step outside
+    the graph -- follows the eager trajectory too, and a batch without ground truth skips the update."""
+    import copy
+    from dsmnet_amd import train
+    from dsmnet_amd.graphs import GraphedTrainStep
+    from dsmnet_amd.models import model_create_by_name
+    torch.manual_seed(0)
+    m1 = model_create_by_name("psmnet", 192).cuda()
+    for i in (1, 2, 3):
+        with torch.no_grad():
+            getattr(m1, "classif%d" % i)[2].weight.mul_(1e-3)
+    m2 = copy.deepcopy(m1)
+    batches = [_batch(1, 256, 512, 6, s) for s in (5, 6, 7)]
+    lf1, lf2 = train.losses("supervised", 1, 0), train.losses("supervised", 1, 0)
+    lf1.Weight_Adjust_levels(0); lf2.Weight_Adjust_levels(0)
+    o1 = torch.optim.Adam(m1.parameters(), lr=1e-4)
+    eager = [train.train_step(m1, o1, lf1, b)[0] for b in batches + batches]
+    o2 = torch.optim.Adam(m2.parameters(), lr=1e-4, capturable=True, fused=True)
+    state = copy.deepcopy(m2.state_dict())
+    step = GraphedTrainStep(m2, o2, lf2, batches[0], warmup=2, flat_gradients=True)
+    assert step.flatgrads is not None and all(p.grad.data_ptr() >= step.flatgrads.flat.data_ptr()
+                                              for p in m2.parameters())
+    m2.load_state_dict(state)                 # the warm-up and the capture ran real steps: rewind
+    for st in o2.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+    graphed = [float(step(b)[0]) for b in batches + batches]
+    for a, b in zip(eager, graphed):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (eager, graphed)
+    assert graphed[-1] < graphed[0]
+    before = [p.detach().clone() for p in m2.parameters()]
+    empty = batches[0].clone()
+    empty[:, 6:7] = 0                          # no ground-truth pixel: zero gradients, no update
+    step(empty)
+    assert float(step.flatgrads.extra) == 0.0
+    assert all(torch.equal(a, b) for a, b in zip(before, m2.parameters()))
