@@ -199,6 +199,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
   };
   auto wload = [&](auto sc_, unsigned wb) {                     // weights of step s (of the chunk at wb)
     constexpr int s = decltype(sc_)::value;
+#if defined(DSM_ZS_ABLATE) && DSM_ZS_ABLATE == 2
+    if (p.B != 12345 && s >= 0 && wb != 0xffffffffu) return;   // timing-only build: weight fragments never loaded
+#endif
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -253,6 +256,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
       float* yv = p.y + ((((long)b * p.Do + zo) * p.Ho + yo) * p.Wo + xo) * 32 + 4 * g;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
+#if defined(DSM_ZS_ABLATE) && DSM_ZS_ABLATE == 7
+        if (p.B == 12345)                       // timing-only build: the epilogue's arithmetic without its stores
+#endif
         *reinterpret_cast<f32x4*>(yv + 16 * a) = v[a];
         track_amax(am, v[a]);
       }
@@ -308,7 +314,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
           xload(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, 3>{}, rd);
         }
       }
+#if !(defined(DSM_ZS_ABLATE) && DSM_ZS_ABLATE == 3)
       if constexpr (s < NPF) pf[s] = buffer_load16(nrsrc, vx[s] >= nxmin ? voff[s] : OOBV, 0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       constexpr int set = 2 - kz;
       if (mask & (1u << kz)) {
@@ -318,12 +326,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
           for (int a = 0; a < 2; ++a) mma16<PM>(acc[set][r][a], wq[s % WRING][a], xq[tp & 1][r]);
       }
       // the operand split of one staged quad of the next chunk, in this step's issue gaps
+#if !(defined(DSM_ZS_ABLATE) && DSM_ZS_ABLATE == 3)
       if constexpr (s >= CONV0) convert(std::integral_constant<int, s - CONV0>{}, wr);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     });
     if (cur.cg == ncg - 1) {                                    // the plane is complete
       const int zo = cur.zi - 1;
+#if defined(DSM_ZS_ABLATE) && DSM_ZS_ABLATE == 1
+      if (zo >= cur.z0 && zo < cur.z1 && p.B == 12345) emit(cur, zo);    // timing-only build: no epilogue
+#else
       if (zo >= cur.z0 && zo < cur.z1) emit(cur, zo);
+#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
