@@ -124,7 +124,8 @@ def test_virtual_volume_equals_the_materialised_one(cv, mode, mask_left, shape, 
         assert maxerr(virt, real) <= LIMITS[mode][0] * real.abs().max().item()
     want = F.conv3d(vol.double(), w.double(), padding=1).relu()
     emax, erms = errors(virt, want)
-    assert emax <= LIMITS[mode][0] and erms <= LIMITS[mode][1], (emax, erms)
+    grow = max(1.0, 2 * C / 64.0) ** 0.5        # the band was measured at K = 27 Cin <= 1728 (see above)
+    assert emax <= LIMITS[mode][0] * grow and erms <= LIMITS[mode][1] * grow, (emax, erms)
 
 
 def test_psmnet_paths_agree(cv, golden_e2e):
