@@ -17,10 +17,10 @@
 //    (one persistent workgroup per CU): no tail round; a range that crosses a column border just
 //    starts a new segment.  Partial sums never leave registers: a segment's first and last
 //    planes run only the z-taps whose output plane lies inside the segment.
-//  * wave (rh, xh) owns rows 4 rh .. 4 rh + 3 and the 16 voxels xh of the tile, all 32 output
-//    channels, on 16x16x32 MFMAs: per (tap position, z-tap) step 2 NP weight fragments (L2, ring
-//    three steps deep) feed 8 product groups; the 4 NP activation fragments of a tap position are read
-//    from LDS once and serve its three z-taps.
+//  * wave (ah, xh) owns output channels 16 ah .. 16 ah + 15 and the 16 columns xh of the tile, all its
+//    rows, on 16x16x32 MFMAs: per (tap position, z-tap) step NP weight fragments (L2, a ring of
+//    nine) feed TY product groups; the TY NP activation fragments of a tap position are read from LDS
+//    once and serve its three z-taps.
 //  * staging: a chunk = one input plane x 32 channels, 10 x 34 voxels x 8 fp32 quads = 11 buffer
 //    loads per thread (zero address VALU: per-column offsets, per-chunk descriptor base), issued
 //    one per step over the first 11 steps; over the last 11 steps each quad is split into its NP
@@ -33,21 +33,33 @@
 //    contiguous bytes, conflict-free under the stores' 32-bank rule (MI355X_MICROARCH.md, LDS).
 //    Two images, one barrier per chunk.  Each voxel is split 1.33 times (once per staging), not
 //    once per tap as in the r01 kernel.
-//  * one workgroup per CU, one wave per SIMD.
+//  * one workgroup per CU with one wave per SIMD (8 x 32 tiles), or two (4 x 32 tiles; the fp16 modes).
 //  * `vol`: the input is a concatenation cost volume that is NEVER MATERIALISED: x is the NHWC
 //    feature tensor (2B, H, W, C) [left images, then right images]; input plane d of the
 //    (B, 2C, D, H, W) volume is staged as [left | right shifted by d voxels] with x < d zeroed
 //    (right half always, left half iff vol_mask_left).
 #pragma once
 
-template <int PM> struct ZsCfg {
+#ifndef DSM_ZS_TILING_F16
+#define DSM_ZS_TILING_F16 1       // the fp16 modes' tiling (V below); 0 in A/B builds
+#endif
+
+// Two tilings: V = 0: 8 x 32 output tile, one workgroup per CU (bf16x3: its two 67.6 KB images fill the
+// LDS); V = 1: 4 x 32 tile, TWO workgroups per CU (<= 256 registers, 2 x 57 KB of LDS in the fp16
+// modes).  One wave per SIMD issues in order: every load, LDS access and VALU instruction of the step
+// takes issue cycles the MFMAs do not get (the kernel loses the same ~90 us to them at six, three or
+// one MFMA per product: profiles/r03_ablation.md); a second resident workgroup issues its MFMAs in
+// those cycles.  At six MFMAs per product the chip is power-bound and the second workgroup buys
+// nothing (r02); at three it does.
+template <int PM, int V> struct ZsCfg {
   static constexpr int NP = Prec<PM>::NP, NPW = Prec<PM>::NPW;
-  static constexpr int TY = 8, IY = TY + 2, IX = 34;
-  static constexpr int NV = IY * IX;                  // 340 voxels of the halo box
-  static constexpr int NPF = (NV * 8 + NTHREADS - 1) / NTHREADS;   // 11 staged quads per thread
-  static constexpr int NVP = 352;                     // units per (plane, g) row: 32 NPF, a multiple of 16
-  static constexpr int ROW = NVP * 16;                // 5,632 B
-  static constexpr int IMG = NP * 4 * ROW;            // 67,584 | 45,056 | 22,528 B
+  static constexpr int TY = V ? 4 : 8, IY = TY + 2, IX = 34;
+  static constexpr int WGS = V ? 2 : 1;               // workgroups per CU
+  static constexpr int NV = IY * IX;                  // 340 | 204 voxels of the halo box
+  static constexpr int NPF = (NV * 8 + NTHREADS - 1) / NTHREADS;   // 11 | 7 staged quads per thread
+  static constexpr int NVP = 32 * NPF;                // units per (plane, g) row: a multiple of 16
+  static constexpr int ROW = NVP * 16;                // 5,632 | 3,584 B
+  static constexpr int IMG = NP * 4 * ROW;            // V = 0: 67,584 | 45,056 | 22,528 B
   static constexpr int LDS = 2 * IMG + 256;           // two images + the folded affine
   static constexpr int NSTEP = 27;
   static constexpr int WSTEP = 2 * NPW * 1024;        // weight bytes per (tap position, z-tap) step
@@ -57,11 +69,12 @@ template <int PM> struct ZsCfg {
   // six-MFMA form only.  The ring has 9 slots (9 divides NSTEP: slot = step % 9 stays consistent
   // across chunks); only WAHEAD + 1 of them are live at a time.
 #ifndef DSM_ZS_WAHEAD
-#define DSM_ZS_WAHEAD (PM == 3 ? 2 : 4)
+#define DSM_ZS_WAHEAD (PM == 3 ? 2 : (V ? 3 : 4))
 #endif
   static constexpr int WRING = 9, WAHEAD = DSM_ZS_WAHEAD;
   static_assert(NSTEP % WRING == 0 && WAHEAD < WRING, "weight ring");
   static_assert(32 * NPF <= NVP && NVP % 16 == 0, "image row");
+  static_assert(WGS * LDS <= 160 * 1024, "LDS");
 };
 
 template <int PM>
@@ -83,17 +96,16 @@ __device__ __forceinline__ void mma16(f32x4& c, const typename Prec<PM>::frag (&
   }
 }
 
-template <int PM>
-__global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
-  using C = ZsCfg<PM>;
+template <int PM, int V>
+__global__ __launch_bounds__(NTHREADS, (ZsCfg<PM, V>::WGS)) void conv_zs_kernel(ZsParams p) {
+  using C = ZsCfg<PM, V>;
   using frag = typename Prec<PM>::frag;
   constexpr int NP = C::NP, NPW = C::NPW, TY = C::TY, IX = C::IX, NV = C::NV, NPF = C::NPF, ROW = C::ROW,
                 IMG = C::IMG, NSTEP = C::NSTEP, WSTEP = C::WSTEP, CONV0 = C::CONV0, WRING = C::WRING, WAHEAD = C::WAHEAD;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int rh = wave >> 1, xh = wave & 1;
-  const int row0 = 4 * rh;                    // the wave's 4 rows of the 8-row tile
+  const int ah = wave >> 1, xh = wave & 1;    // this wave's 16 output channels (16 ah ..) and 16 columns, all TY rows
   const int ncg = p.Cin >> 5;
 
   // this workgroup's range of the linearised (column, output plane) space; workgroups on one XCD
@@ -114,12 +126,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
   float* const aff = reinterpret_cast<float*>(lds_raw + 2 * IMG);
   if (tid < 64) aff[tid] = tid < 32 ? (p.scale ? p.scale[tid] * so : so) : (p.shift ? p.shift[tid - 32] : 0.f);
   __syncthreads();
-  f32x4 sc[2], sh[2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    sc[a] = *reinterpret_cast<const f32x4*>(aff + 16 * a + 4 * g);
-    sh[a] = *reinterpret_cast<const f32x4*>(aff + 32 + 16 * a + 4 * g);
-  }
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(aff + 16 * ah + 4 * g);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(aff + 32 + 16 * ah + 4 * g);
   float am = 0.f;
 
   // ---- chunk iterator: live (input plane, channel group) pairs of the segments of [u_begin, u_end)
@@ -182,20 +190,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
   const unsigned lane16 = lane * 16u;
   // LDS slot of this thread's quads: unit g = sq & 3, half = sq >> 2, voxel sv + 32 k
   const int st_off = (lane >> 4) * ROW + sv * 16 + (lane & 1) * 8;                 // + 512 k, + plane * 4 ROW
-  // activation fragment of this lane: voxel (row0 + r + ky, 16 xh + j + kx), unit g, plane q
-  const int rd_off = g * ROW + (row0 * IX + 16 * xh + j) * 16;
+  // activation fragment of this lane: voxel (r + ky, 16 xh + j + kx), unit g, plane q
+  const int rd_off = g * ROW + (16 * xh + j) * 16;
 
-  f32x4 acc[3][4][2];
-  frag xq[2][4][NP];            // [tap-position parity][row][plane]
-  frag wq[WRING][2][NP];        // [step % WRING][a][plane]
+  f32x4 acc[3][TY];
+  frag xq[2][TY][NP];           // [tap-position parity][row][plane]
+  frag wq[WRING][NP];           // [step % WRING][plane]: this wave's 16-channel block only
   f32x4 pf[NPF];
 
   auto zero_set = [&](auto sc_) {
     constexpr int s = decltype(sc_)::value;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int a = 0; a < 2; ++a) acc[s][r][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < TY; ++r) acc[s][r] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto wload = [&](auto sc_, unsigned wb) {                     // weights of step s (of the chunk at wb)
     constexpr int s = decltype(sc_)::value;
@@ -203,11 +209,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
     if (p.B != 12345 && s >= 0 && wb != 0xffffffffu) return;   // timing-only build: weight fragments never loaded
 #endif
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int q = 0; q < NP; ++q)
-        wq[s % WRING][a][q] = __builtin_bit_cast(
-            frag, buffer_load16(wrsrc, lane16, wb + s * WSTEP + (a * NPW + q) * 1024));
+    for (int q = 0; q < NP; ++q)
+      wq[s % WRING][q] = __builtin_bit_cast(
+          frag, buffer_load16(wrsrc, lane16 + (unsigned)ah * (NPW * 1024), wb + s * WSTEP + q * 1024));
   };
   auto xload = [&](auto tpc, auto rc, const unsigned char* rd) {
     constexpr int tp = decltype(tpc)::value, r = decltype(rc)::value;
@@ -235,33 +239,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
     const int xo = tx * 32 + 16 * xh + j;
     if (xo >= p.Wo) return;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int yo = ty * TY + row0 + r;
+    for (int r = 0; r < TY; ++r) {
+      const int yo = ty * TY + r;
       if (yo >= p.Ho) continue;
-      f32x4 v[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        v[a] = acc[0][r][a] * sc[a] + sh[a];
-        if (p.relu == 2) { v[a].x = fmaxf(v[a].x, 0.f); v[a].y = fmaxf(v[a].y, 0.f); v[a].z = fmaxf(v[a].z, 0.f); v[a].w = fmaxf(v[a].w, 0.f); }
-      }
-      if (p.res) {
-        const float* rv = p.res + ((((long)b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo) * 32 + 4 * g;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) v[a] += *reinterpret_cast<const f32x4*>(rv + 16 * a);
-      }
-      if (p.relu == 1) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) { v[a].x = fmaxf(v[a].x, 0.f); v[a].y = fmaxf(v[a].y, 0.f); v[a].z = fmaxf(v[a].z, 0.f); v[a].w = fmaxf(v[a].w, 0.f); }
-      }
-      float* yv = p.y + ((((long)b * p.Do + zo) * p.Ho + yo) * p.Wo + xo) * 32 + 4 * g;
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
+      f32x4 v = acc[0][r] * sc + sh;
+      if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (p.res)
+        v += *reinterpret_cast<const f32x4*>(p.res + ((((long)b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo) * 32 + 16 * ah + 4 * g);
+      if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
 #if defined(DSM_ZS_ABLATE) && DSM_ZS_ABLATE == 7
-        if (p.B == 12345)                       // timing-only build: the epilogue's arithmetic without its stores
+      if (p.B == 12345)                       // timing-only build: the epilogue's arithmetic without its stores
 #endif
-        *reinterpret_cast<f32x4*>(yv + 16 * a) = v[a];
-        track_amax(am, v[a]);
-      }
+      *reinterpret_cast<f32x4*>(p.y + ((((long)b * p.Do + zo) * p.Ho + yo) * p.Wo + xo) * 32 + 16 * ah + 4 * g) = v;
+      track_amax(am, v);
     }
   };
 
@@ -297,7 +287,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
       const int zo = cur.zi - kz + 1;
       if (zo >= cur.z0 && zo < cur.z1) mask |= 1u << kz;
     }
-    static_for<0, 4>([&](auto rc) { xload(std::integral_constant<int, 0>{}, rc, rd); });
+    static_for<0, TY>([&](auto rc) { xload(std::integral_constant<int, 0>{}, rc, rd); });
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, NSTEP>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
@@ -306,13 +296,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
       if constexpr (s + WAHEAD < NSTEP) wload(std::integral_constant<int, s + WAHEAD>{}, wcur);
       else wload(std::integral_constant<int, s + WAHEAD - NSTEP>{}, wnext);
       if constexpr (tp + 1 < 9) {
-        if constexpr (kz == 0) {
-          xload(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, 0>{}, rd);
-          xload(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, 1>{}, rd);
-        } else if constexpr (kz == 1) {
-          xload(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, 2>{}, rd);
-          xload(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, 3>{}, rd);
-        }
+        if constexpr (kz < 2)             // the next tap position's TY row fragments, half per step
+          static_for<0, TY / 2>([&](auto rc) {
+            xload(std::integral_constant<int, tp + 1>{}, std::integral_constant<int, (TY / 2) * kz + decltype(rc)::value>{}, rd);
+          });
       }
 #if !(defined(DSM_ZS_ABLATE) && DSM_ZS_ABLATE == 3)
       if constexpr (s < NPF) pf[s] = buffer_load16(nrsrc, vx[s] >= nxmin ? voff[s] : OOBV, 0);
@@ -321,9 +308,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
       constexpr int set = 2 - kz;
       if (mask & (1u << kz)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int a = 0; a < 2; ++a) mma16<PM>(acc[set][r][a], wq[s % WRING][a], xq[tp & 1][r]);
+        for (int r = 0; r < TY; ++r) mma16<PM>(acc[set][r], wq[s % WRING], xq[tp & 1][r]);
       }
       // the operand split of one staged quad of the next chunk, in this step's issue gaps
 #if !(defined(DSM_ZS_ABLATE) && DSM_ZS_ABLATE == 3)
@@ -339,9 +324,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_zs_kernel(ZsParams p) {
       if (zo >= cur.z0 && zo < cur.z1) emit(cur, zo);
 #endif
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int a = 0; a < 2; ++a) { acc[0][r][a] = acc[1][r][a]; acc[1][r][a] = acc[2][r][a]; }
+      for (int r = 0; r < TY; ++r) { acc[0][r] = acc[1][r]; acc[1][r] = acc[2][r]; }
       zero_set(std::integral_constant<int, 2>{});
       if (cur.zi == cur.zhi) {                                  // segment ends
         if (cur.zhi >= cur.z0 && cur.zhi < cur.z1) emit(cur, cur.zhi);   // only when z1 = Di: no plane Di follows
@@ -381,9 +364,9 @@ __global__ void pack_weights_zs_kernel(const float* __restrict__ w, unsigned sho
   for (int q = 0; q < NPW; ++q) o[(long)q * 64 * 8] = (unsigned short)(pl[q] & 0xffffu);
 }
 
-template <int PM>
+template <int PM, int V = (PM == 3 ? 0 : DSM_ZS_TILING_F16)>
 int launch_conv_zs(ZsParams p, int grid, hipStream_t s) {
-  using C = ZsCfg<PM>;
+  using C = ZsCfg<PM, V>;
   p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, C::TY);
   const long ncol = (long)p.B * p.nty * p.ntx;
   DSM_REQUIRE(ncol < (1L << 30), DSM_ERR_UNSUPPORTED);
@@ -391,13 +374,13 @@ int launch_conv_zs(ZsParams p, int grid, hipStream_t s) {
   p.nunits = ncol * p.Do;
   static thread_local bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute((const void*)conv_zs_kernel<PM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv_zs_kernel<PM, V>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             C::LDS) != hipSuccess)
       return DSM_ERR_LAUNCH;
     configured = true;
   }
-  int blocks = grid > 0 ? grid : 256;                          // persistent workgroups: one per CU
+  int blocks = grid > 0 ? grid : 256 * C::WGS;                 // persistent workgroups: WGS per CU
   if ((long)blocks > p.nunits) blocks = (int)p.nunits;
-  hipLaunchKernelGGL(conv_zs_kernel<PM>, dim3(blocks), dim3(NTHREADS), C::LDS, s, p);
+  hipLaunchKernelGGL((conv_zs_kernel<PM, V>), dim3(blocks), dim3(NTHREADS), C::LDS, s, p);
   return dsm_launch_status();
 }
