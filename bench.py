@@ -45,6 +45,11 @@ PEAK_HBM_GBS = 8000.0
 HBM_COPY_CEILING_GBS = 6290.0      # measured float4 copy (same guide); reported beside the spec fraction
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 / fp16 MFMA peak
+# what a bare v_mfma_f32_16x16x32_f16 loop sustains on every SIMD of this chip with non-zero operands
+# (scripts/micro/mfma_ceiling.hip, profiles/r03_mfma_ceiling.md: 1385-1503 with one wave per SIMD,
+# 1615-1626 with two; 2007 on all-zero operands -- the clock follows the power the data draws);
+# reported beside the spec fraction, as the copy ceiling is for the HBM kernels
+MFMA_SUSTAINED_TFLOPS = 1626.0
 # MFMAs a product costs on the split kernels: bf16x3 (three bf16 terms, six of nine cross terms),
 # f16x2 (two fp16 terms, three cross terms), f16 (operands rounded to fp16)
 SPLIT_MFMAS = (("bf16x3", 6, "bf16 (3-term split of fp32 operands, 6 MFMAs per product, fp32 accumulate)"),
@@ -109,6 +114,7 @@ def kernel_rooflines(summary, steps):
             extra = {"mfma_dtype": split[2], "mfmas_per_product": split[1],
                      "mfma_tflops_executed": round(achieved * split[1], 1),
                      "mfma_peak_16bit": PEAK_BF16_MFMA_TFLOPS,
+                     "frac_of_sustained_mfma": round(achieved * split[1] / MFMA_SUSTAINED_TFLOPS, 4),
                      "x_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 3)}
         elif mfma:
             achieved, peak, unit, bound = per_launch / avg_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s", "mfma"

@@ -135,7 +135,7 @@ def _run_conv2d_autograd(conv, bn, x, residual, relu):
                                1 if relu else 0, momentum, bn.eps)
         if bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
-        blocks3d.invalidate_folded_caches()   # running statistics changed through raw pointers
+        blocks3d._bump_running_stats(bn)      # running statistics changed through raw pointers
         return out
     if bn is not None:
         y = bn(y)

@@ -32,6 +32,15 @@ def invalidate_folded_caches():
     _EPOCH[0] += 1
 
 
+def _bump_running_stats(bn):
+    """The BN kernels update the running statistics through raw pointers: bump the two tensors'
+    version counters by hand, so that exactly the folds made from THIS layer's statistics are re-made
+    at the next eval forward (a global invalidation would re-pack every layer after every step)."""
+    if bn.track_running_stats and bn.running_mean is not None:
+        torch.autograd.graph.increment_version(bn.running_mean)
+        torch.autograd.graph.increment_version(bn.running_var)
+
+
 def _versions(*tensors):
     return tuple((t.data_ptr(), t._version) for t in tensors if t is not None) + (_EPOCH[0],)
 
@@ -104,9 +113,7 @@ def _run_block_batch_stats(folded, conv, bn, x, residual, relu):
                                relu, momentum, bn.eps)
         if bn.num_batches_tracked is not None:
             bn.num_batches_tracked += 1
-        # the kernel updated the running statistics through raw pointers (no version bump):
-        # every eval-mode fold made from them is stale now
-        invalidate_folded_caches()
+        _bump_running_stats(bn)
         if _TRAIN_RELU_HOOK[0] is not None and relu != RELU_NONE:
             _TRAIN_RELU_HOOK[0](out, relu)
         return out
