@@ -18,6 +18,7 @@ DSM_F32 = 0
 DSM_NCDHW, DSM_NDHWC = 0, 1
 DSM_CONV_FP32_MFMA, DSM_CONV_COUT1_CHUNKED, DSM_CONV_TM_SHIFT, DSM_CONV_BLOCKS_SHIFT = 1, 2, 4, 16
 DSM_CONV_NO_NSPLIT = 4
+DSM_CONV_NO_ONCE = 8
 DSM_PREC_F32, DSM_PREC_F16, DSM_PREC_F16X2 = 0, 1, 2
 
 

@@ -1068,6 +1068,9 @@ int make_plan_f32(const dsm_conv3d_args* a, Plan* pl) {
     if (kd == 1 && TM == 2 && dil == 1 && (NT == 2 || NT == 4) && tiles8 <= 256 &&
         !(a->flags & DSM_CONV_NO_NSPLIT)) {
       pl->NT = NT / 2; pl->nsplit = 2;
+      // 64 -> 64 (the towers' 31 launches at 1/4 resolution): the single-tile form, every chunk of the
+      // tile requested up front (conv_once_kernel)
+      if (NT == 2 && a->Cin == 64 && !(a->flags & DSM_CONV_NO_ONCE)) pl->once = 1;
     }
     // the 64-channel 3-D layers on 4-row tiles (the bottom of the hourglass: 216 tiles, one serial chain
     // of 1,296 MFMAs per wave): two columns of 32 channels halve the chain
@@ -1111,6 +1114,7 @@ int make_plan(const dsm_conv3d_args* a, Plan* pl) {
     DSM_REQUIRE(a->x_amax != nullptr, DSM_ERR_ARG);      // the input's absolute maximum (device scalar)
     pl->pm = a->precision == DSM_PREC_F16X2 ? 2 : 1;
   }
+  if (pl->pm == 3) pl->once = 0;                         // the single-tile form exists in the fp16 modes only
   return DSM_OK;
 }
 }  // namespace
@@ -1134,6 +1138,7 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
       if (pl.KZ == 3 && pl.S == 2) snprintf(buf, len, "conv3d_%s_mfma_kernel<S=2,NT=%d,TM=%d>", pr, pl.NT, pl.TM);
       else if (pl.KZ == 3 && pl.nsplit > 1) snprintf(buf, len, "conv3d_%s_mfma_kernel<NT=%d,TM=%d>x%d", pr, pl.NT, pl.TM, pl.nsplit);
       else if (pl.KZ == 3) snprintf(buf, len, "conv3d_%s_mfma_kernel<NT=%d,TM=%d>", pr, pl.NT, pl.TM);
+      else if (pl.once) snprintf(buf, len, "conv2d_%s_mfma_kernel<NT=%d,TM=%d,DIL=%d>x%d,once", pr, pl.NT, pl.TM, pl.DIL, pl.nsplit);
       else if (pl.nsplit > 1) snprintf(buf, len, "conv2d_%s_mfma_kernel<NT=%d,TM=%d,DIL=%d>x%d", pr, pl.NT, pl.TM, pl.DIL, pl.nsplit);
       else snprintf(buf, len, "conv2d_%s_mfma_kernel<NT=%d,TM=%d,DIL=%d>", pr, pl.NT, pl.TM, pl.DIL);
       break;

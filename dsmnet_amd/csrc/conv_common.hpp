@@ -26,7 +26,7 @@ struct ConvParams {
 // One place decides the kernel variant; dsm_conv3d_fwd launches it, dsm_conv3d_plan names it.
 // kind: 0 conv, 1 deconv, 2 conv cout1, 3 deconv cout1, 4 conv cout1 z-sliding, 5 conv split (bf16x3 / f16x2 / f16), 6 deconv split,
 //       7 z-sliding conv (Cout = 32, stride 1; conv_zs.hpp)
-struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; int nsplit = 1; int pm = 3; };
+struct Plan { int kind; int S, NT, TM, CK; int KZ, K, DIL; int nsplit = 1; int pm = 3; int once = 0; };
 
 // the z-sliding kernel (conv_zs.hpp, plan kind 7)
 struct ZsParams {

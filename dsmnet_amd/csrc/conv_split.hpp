@@ -444,6 +444,179 @@ void conv_split_kernel(ConvParams p) {
 }
 
 // ----------------------------------------------------------------------------
+// The single-tile form of the 2-D 3x3 stride-1 convolution: conv_once_kernel.
+// PSMNet's 1/4-resolution towers (submodule.py:24-46,108-118: 31 Conv2d(64, 64, 3) launches at
+// 2 x 96 x 320) give conv_split_kernel ONE round of 240 tiles: a workgroup lives for one tile of
+// NCH = Cin / 16 = 4 chunks, each ~0.7 us of MFMAs -- shorter than the memory latency of the next
+// chunk's loads, which it requests one chunk ahead.  The tile is then a chain of five exposed
+// latencies (first chunk, then one per chunk): 21.8 us per launch for ~6 us of MFMAs.  Here every
+// chunk of the tile is requested up front (NCH x NPF loads per thread in flight, NCH known at compile
+// time, the chunk loop fully unrolled): in-order return hands chunk 0 over first, chunks 1.. arrive
+// while chunk 0 is split and multiplied.  One exposed latency per tile.  Everything else -- LDS images,
+// fragment order, weight ring, operand split riding in the MFMA gaps, epilogue, packed weights -- is
+// conv_split_kernel's; results are the same bits.
+// ----------------------------------------------------------------------------
+#ifndef DSM_ONCE_OFF
+#define DSM_ONCE_OFF 0          // timing-only A/B builds: 1 no MFMAs, 2 no activation loads, 4 no stores, 8 no weight loads, 16 no split
+#endif
+template <int PM, int NT, int TM, int NCH, int NSPLIT>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_once_kernel(ConvParams p) {
+  using C = ConvSplitCfg<PM, NT, TM, 1, 1, 1, NSPLIT>;
+  using frag = typename Prec<PM>::frag;
+  static_assert(C::TWO, "two workgroups per CU");
+  constexpr int NP = C::NP, NPW = C::NPW, TY = C::TY, CK = C::CK, IX = C::IX, NE = C::NE,
+                NPF = C::NPF, PITCH = C::PITCH, RP = C::RP, IMG = C::IMG, NTP = C::NTP, COUT = C::COUT;
+  constexpr int NITEM = 9, NGROUP = NITEM * TM, AHEAD = 3;
+  constexpr int CPG = (2 * NPF + NGROUP - 1) / NGROUP;      // split halves per product group
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n0 = NSPLIT > 1 ? (int)blockIdx.y * NT : 0;
+  const int t = blockIdx.x;
+  if (t >= p.ntiles) return;
+  const SplitScale ss = split_scale<PM>(p);
+
+  int id = t;
+  const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
+  const int ty0 = (id % p.nty) * TY; id /= p.nty;
+  const int tz = id % p.Do, tb = id / p.Do;
+  const int yb = ty0 - 1, xb = tx0 - 1;
+  const unsigned base = (unsigned)(4l * (((((long)tb * p.Di + tz) * p.Hi + yb) * p.Wi + xb) * p.Cin));
+  constexpr unsigned OOBV = 0x80000000u;
+  unsigned voff[NPF];
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) {
+    const int e = tid + k * NTHREADS;
+    const int v = e / 4, q = e % 4;
+    const int yy = v / IX, xx = v % IX;
+    const int y = yb + yy, x = xb + xx;
+    const bool ok = e < NE && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+    voff[k] = ok ? base + 4u * (unsigned)((yy * p.Wi + xx) * p.Cin + 4 * q) : OOBV;
+  }
+  // every chunk of the tile, requested now: chunk-major, so that chunk 0 is the first to arrive
+  f32x4 pf[NCH][NPF];
+  static_for<0, NCH>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const char*>(p.x) + c * (CK * 4), p.xbytes);
+    static_for<0, NPF>([&](auto kc) {
+      if ((DSM_ONCE_OFF & 2) && p.B != 12345) pf[c][decltype(kc)::value] = f32x4{1.f, 2.f, 3.f, 4.f};
+      else pf[c][decltype(kc)::value] = buffer_load16(rs, voff[decltype(kc)::value], 0);
+    });
+  });
+  const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.wbytes);
+  const int wr_off = (tid >> 2) * PITCH + (tid & 3) * 8;
+  const int rd_off = ((wave * TM) * RP + r) * PITCH + h * 16;
+  const unsigned lane16 = lane * 16u;
+  f32x16 acc[TM][NT];
+  frag wq[AHEAD][NT][NP];
+  unsigned half_a[NP];
+  auto convert = [&](auto cc, auto kc, auto hc, unsigned char* img) {
+    constexpr int c = decltype(cc)::value, k = decltype(kc)::value, half = decltype(hc)::value;
+    if ((DSM_ONCE_OFF & 16) && p.B != 12345 && k >= 0) return;
+    unsigned pl[NP];
+    split_pair<PM>(half ? pf[c][k].z : pf[c][k].x, half ? pf[c][k].w : pf[c][k].y, ss.sx, pl);
+    if constexpr (half == 0) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) half_a[q] = pl[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        u32x2 v; v.x = half_a[q]; v.y = pl[q];
+        if (k < NPF - 1 || tid < NE - (NPF - 1) * NTHREADS)
+          *reinterpret_cast<u32x2*>(img + wr_off + k * (64 * PITCH) + q * 32) = v;
+      }
+    }
+  };
+  auto wload = [&](auto ic, unsigned wb) {
+    constexpr int item = decltype(ic)::value;
+    if ((DSM_ONCE_OFF & 8) && p.B != 12345 && item >= 0) return;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+        wq[item % AHEAD][n][q] = __builtin_bit_cast(
+            frag, buffer_load16(wrsrc, lane16, wb + ((item * NTP + n) * NPW + q) * (64 * 16)));
+  };
+  auto wbase_of = [&](int c) { return (unsigned)(c * 9) * (NTP * NPW * 64 * 16) + (unsigned)n0 * (NPW * 64 * 16); };
+
+  float* const aff = reinterpret_cast<float*>(lds_raw + 2 * IMG);
+  stage_affine_lds(aff, p.scale, p.shift, COUT, tid, ss.out);
+  float am = 0.f;
+  static_for<0, AHEAD - 1>([&](auto ic) { wload(ic, wbase_of(0)); });
+  static_for<0, NPF>([&](auto kc) {
+    convert(std::integral_constant<int, 0>{}, kc, std::integral_constant<int, 0>{}, lds_raw);
+    convert(std::integral_constant<int, 0>{}, kc, std::integral_constant<int, 1>{}, lds_raw);
+  });
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+  static_for<0, NCH>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    __syncthreads();            // image c & 1 is complete; everyone is done reading the other one
+    const unsigned char* const rd = lds_raw + (c & 1) * IMG + rd_off;
+    unsigned char* const nimg = lds_raw + ((c + 1) & 1) * IMG;
+    const unsigned wchunk = wbase_of(c), wnext = wbase_of(c + 1 < NCH ? c + 1 : c);
+    frag xq[2][NP];
+    auto xload = [&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int item = s / TM, m = s % TM;
+      constexpr int vo = (m + item / 3) * RP + item % 3;
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+        xq[s & 1][q] = *reinterpret_cast<const frag*>(rd + vo * PITCH + q * 32);
+    };
+    xload(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, NITEM>([&](auto ic) {
+      constexpr int item = decltype(ic)::value;
+      if constexpr (item + AHEAD - 1 < NITEM) wload(std::integral_constant<int, item + AHEAD - 1>{}, wchunk);
+      else wload(std::integral_constant<int, item + AHEAD - 1 - NITEM>{}, wnext);
+      static_for<0, TM>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int s = item * TM + m;
+        if constexpr (s + 1 < NGROUP) xload(std::integral_constant<int, s + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          if (!(DSM_ONCE_OFF & 1) || p.B == 12345) mma32<PM>(acc[m][n], wq[item % AHEAD][n], xq[s & 1]);
+        // the next chunk (long since requested) is split into the other image in this group's gaps
+        if constexpr (c + 1 < NCH) {
+          static_for<0, CPG>([&](auto jc) {
+            constexpr int hidx = s * CPG + decltype(jc)::value;
+            if constexpr (hidx < 2 * NPF)
+              convert(std::integral_constant<int, (c + 1 < NCH ? c + 1 : c)>{}, std::integral_constant<int, hidx / 2>{},
+                      std::integral_constant<int, hidx % 2>{}, nimg);
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  });
+  const int xo = tx0 + r;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int cbase = (n0 + n) * 32 + 4 * h;
+    const Affine af = load_affine_lds(aff, COUT, cbase);
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      const int yo = ty0 + wave * TM + m;
+      if (yo >= p.Ho || xo >= p.Wo) continue;
+      if ((DSM_ONCE_OFF & 4) && p.B != 12345) continue;
+      const long vox = (((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo;
+      const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
+      store_tile<COUT>(acc[m][n], af, p.relu, p.y + vox * COUT + cbase,
+                       p.res ? p.res + rvox * COUT + cbase : nullptr, am);
+    }
+  }
+  flush_amax(p.y_amax, am, reinterpret_cast<float*>(lds_raw));
+}
+
+// ----------------------------------------------------------------------------
 // ConvTranspose3d(k3, s2, p1, op1) on the bf16 pipe (bf16x3, as conv_bf16x3_kernel above).
 // Work item = (input tile 4 rows x 32 columns at depth m, z-parity pz), as in
 // deconv3d_mfma_kernel: wave w owns input row w, its four (py, px) output classes are 32x32
@@ -727,6 +900,18 @@ int run_conv_split(ConvParams p, hipStream_t s) {
                       (C::TWO ? 512 : 256) / NSPLIT, NSPLIT);
 }
 
+template <int PM, int NT, int TM, int NCH, int NSPLIT>
+int run_conv_once(ConvParams p, hipStream_t s) {
+  using C = ConvSplitCfg<PM, NT, TM, 1, 1, 1, NSPLIT>;
+  p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, C::TY);
+  const long nt = (long)p.B * p.Do * p.nty * p.ntx;
+  if (nt >= (1L << 30) || p.Cin != 16 * NCH) return DSM_ERR_UNSUPPORTED;
+  p.ntiles = (int)nt;
+  static_assert(C::LDS <= 64 * 1024, "no dynamic-LDS attribute needed");
+  hipLaunchKernelGGL((conv_once_kernel<PM, NT, TM, NCH, NSPLIT>), dim3((unsigned)nt, NSPLIT), dim3(NTHREADS), C::LDS, s, p);
+  return dsm_launch_status();
+}
+
 template <int PM, int NT>
 int run_deconv_split(ConvParams p, hipStream_t s) {
   using C = DeconvSplitCfg<PM, NT>;
@@ -743,6 +928,13 @@ int dispatch_split(const Plan& pl, const ConvParams& p, hipStream_t s) {
   if (pl.kind == 6) return pl.NT == 1 ? run_deconv_split<PM, 1>(p, s) : run_deconv_split<PM, 2>(p, s);
   if (pl.kind != 5) return DSM_ERR_UNSUPPORTED;
   if (pl.S == 2) return run_conv_split<PM, 2, 1, 3, 1, 2>(p, s);
+  if constexpr (PM != 3) {                      // (bf16x3's three-plane images do not leave room)
+    if (pl.once) {                              // one round of tiles, every chunk requested up front
+      if (pl.KZ == 1 && pl.NT == 1 && pl.TM == 2 && pl.DIL == 1 && pl.nsplit == 2 && p.Cin == 64)
+        return run_conv_once<PM, 1, 2, 4, 2>(p, s);
+      return DSM_ERR_UNSUPPORTED;
+    }
+  }
   if (pl.nsplit == 2) {                         // 2-D layers of 64 / 128 channels in two workgroup columns
     if (pl.KZ == 1 && pl.NT == 1 && pl.TM == 2 && pl.DIL == 1) return run_conv_split<PM, 1, 2, 1, 1, 1, 2>(p, s);
     if (pl.KZ == 1 && pl.NT == 2 && pl.TM == 2 && pl.DIL == 1) return run_conv_split<PM, 2, 2, 1, 1, 1, 2>(p, s);

@@ -11,6 +11,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--modes", default="bf16x3,f16x2,f16")
 ap.add_argument("--rep", type=int, default=30)
 ap.add_argument("--only", default="")
+ap.add_argument("--graph", action="store_true", help="REP launches captured into one hipGraph and replayed: GPU time per launch (small kernels are host-bound when launched eagerly)")
+ap.add_argument("--flags", default="0,%d" % _lib.DSM_CONV_NO_NSPLIT, help="conv_flags variants, e.g. 0,4,16 (16 = 4-row tiles)")
 args = ap.parse_args()
 
 # name, kind, cin, cout, stride, transposed, dil, shape (B, [D,] H, W)
@@ -34,6 +36,21 @@ LAYERS = [
 def bench(fn, rep):
     for _ in range(3):
         fn()
+    if args.graph:
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(rep):
+                fn()
+        g.replay()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(5):
+            g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / (5 * rep) * 1e3
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     a.record()
@@ -44,8 +61,7 @@ def bench(fn, rep):
     return a.elapsed_time(b) / rep * 1e3
 
 
-variants = [(m, f, t) for m in args.modes.split(",")
-            for f, t in ((0, ""), (_lib.DSM_CONV_NO_NSPLIT, " nosplit"))]
+variants = [(m, int(f), " f=%s" % f if int(f) else "") for m in args.modes.split(",") for f in args.flags.split(",")]
 print("%-30s" % "layer" + "".join("%16s" % (m + t) for m, f, t in variants))
 for name, kind, cin, cout, stride, tr, dil, shape in LAYERS:
     if args.only and args.only not in name:
