@@ -1159,6 +1159,7 @@ extern "C" int dsm_conv3d_fwd(const dsm_conv3d_args* a, dsm_stream_t stream) {
   p.x_amax = a->x_amax; p.w_amax = nullptr; p.y_amax = a->y_amax;
   p.shift = a->shift; p.res = (const float*)a->residual; p.y = (float*)a->y;
   p.force_blocks = (a->flags >> DSM_CONV_BLOCKS_SHIFT) & 0xffff;
+  p.single_kind = (a->flags & DSM_CONV_NO_ONCE) ? 1 : 0;
   p.B = a->B; p.Cin = a->Cin; p.Cout = a->Cout;
   p.Di = a->Di; p.Hi = a->Hi; p.Wi = a->Wi; p.Do = a->Do; p.Ho = a->Ho; p.Wo = a->Wo;
   p.Dr = a->Dr; p.Hr = a->Hr; p.Wr = a->Wr; p.relu = a->relu;

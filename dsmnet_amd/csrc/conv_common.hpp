@@ -10,6 +10,7 @@ struct ConvParams {
   const float* x; const float* w; const float* scale; const float* shift;
   const float* res; float* y;
   int force_blocks;           // 0, or the persistent grid size asked for in dsm_conv3d_args.flags
+  int single_kind;            // dsm_conv3d_args.flags & DSM_CONV_NO_ONCE: the chunk-pipelined single-kind kernels (A/B runs)
   int B, Cin, Cout;
   int Di, Hi, Wi, Do, Ho, Wo, Dr, Hr, Wr;
   int relu;
@@ -118,6 +119,20 @@ __device__ __forceinline__ void flush_amax(float* slot, float am, float* lds4) {
       atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, am));
   }
 }
+// the same for a workgroup of eight waves (the kernels with MFMA waves and staging waves)
+__device__ __forceinline__ void flush_amax8(float* slot, float am, float* lds8) {
+  if (!slot) return;                                   // uniform
+#pragma unroll
+  for (int o = 32; o; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds8[threadIdx.x >> 6] = am;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    am = fmaxf(fmaxf(fmaxf(lds8[0], lds8[1]), fmaxf(lds8[2], lds8[3])), fmaxf(fmaxf(lds8[4], lds8[5]), fmaxf(lds8[6], lds8[7])));
+    if (am > __builtin_nontemporal_load(slot))
+      atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, am));
+  }
+}
 __device__ __forceinline__ void track_amax(float& am, const f32x4 v) {
   am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
@@ -160,25 +175,41 @@ __device__ __forceinline__ Affine load_affine(const float* __restrict__ scale,
   return a;
 }
 
+// The epilogue of one 32-voxel x 32-channel accumulator tile, in two halves: `load_residual` requests the
+// skip tensor's values, `store_tile` finishes and stores.  A kernel with several tiles per epilogue
+// (rows, output blocks, the four classes of the transposed convolution) calls load_residual for ALL
+// of them first: left to one call per tile, the next tile's loads cannot move above the previous
+// tile's stores (they may alias as far as the compiler knows), and every tile exposes a full memory
+// latency -- the transposed 64 -> 32 kernel spent most of its 170 us there (profiles/r03_ablation.md, 5).
+struct Residual { f32x4 v[4]; };
+__device__ __forceinline__ void load_residual(Residual& r, const float* __restrict__ rv) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) r.v[g] = *reinterpret_cast<const f32x4*>(rv + 8 * g);
+}
 template <int COUT>
 __device__ __forceinline__ void store_tile(const f32x16& acc, const Affine& af, int relu,
-                                           float* __restrict__ yv, const float* __restrict__ rv, float& am) {
-  f32x4 r4[4];
-  if (rv) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) r4[g] = *reinterpret_cast<const f32x4*>(rv + 8 * g);
-  }
+                                           float* __restrict__ yv, const Residual& res, bool has_res, float& am) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const f32x4 sc = af.sc[g], sh = af.sh[g];
     f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
     v = v * sc + sh;
     if (relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (rv) v += r4[g];
+    if (has_res) v += res.v[g];
     if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     *reinterpret_cast<f32x4*>(yv + 8 * g) = v;
     track_amax(am, v);
   }
+}
+// one tile, residual requested and consumed on the spot (the fp32-input kernels, single-tile epilogues)
+template <int COUT>
+__device__ __forceinline__ void store_tile(const f32x16& acc, const Affine& af, int relu,
+                                           float* __restrict__ yv, const float* __restrict__ rv, float& am) {
+  Residual r;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) r.v[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (rv) load_residual(r, rv);
+  store_tile<COUT>(acc, af, relu, yv, r, rv != nullptr, am);
 }
 
 // ----------------------------------------------------------------------------

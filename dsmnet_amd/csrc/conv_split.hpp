@@ -421,18 +421,32 @@ void conv_split_kernel(ConvParams p) {
       const int ty0 = (id % p.nty) * TY; id /= p.nty;
       const int tz = id % p.Do, tb = id / p.Do;
       const int xo = tx0 + r;
+      // per output block: the skip values of RB rows first, then their stores (conv_common.hpp,
+      // load_residual); RB = all rows where the registers allow
+      constexpr int RB = (PM == 3 && NT >= 2) ? 1 : TM;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int cbase = (n0 + n) * 32 + 4 * h;
         const Affine af = load_affine_lds(aff, COUT, cbase);
 #pragma unroll
-        for (int m = 0; m < TM; ++m) {
-          const int yo = ty0 + wave * TM + m;
-          if (yo >= p.Ho || xo >= p.Wo) continue;
-          const long vox = (((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo;
-          const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
-          store_tile<COUT>(acc[m][n], af, p.relu, p.y + vox * COUT + cbase,
-                           p.res ? p.res + rvox * COUT + cbase : nullptr, am);
+        for (int m0 = 0; m0 < TM; m0 += RB) {
+          Residual rr[RB];
+          if (p.res) {
+#pragma unroll
+            for (int mi = 0; mi < RB; ++mi) {
+              const int yo = ty0 + wave * TM + m0 + mi;
+              if (yo >= p.Ho || xo >= p.Wo) continue;
+              const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
+              load_residual(rr[mi], p.res + rvox * COUT + cbase);
+            }
+          }
+#pragma unroll
+          for (int mi = 0; mi < RB; ++mi) {
+            const int yo = ty0 + wave * TM + m0 + mi;
+            if (yo >= p.Ho || xo >= p.Wo) continue;
+            const long vox = (((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo;
+            store_tile<COUT>(acc[m0 + mi][n], af, p.relu, p.y + vox * COUT + cbase, rr[mi], p.res != nullptr, am);
+          }
         }
       }
     }
@@ -602,18 +616,244 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_once_kernel(ConvParams p) {
   for (int n = 0; n < NT; ++n) {
     const int cbase = (n0 + n) * 32 + 4 * h;
     const Affine af = load_affine_lds(aff, COUT, cbase);
+    Residual rr[TM];            // every row's skip values first, then the stores (conv_common.hpp)
+    if (p.res) {
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        const int yo = ty0 + wave * TM + m;
+        if (yo >= p.Ho || xo >= p.Wo) continue;
+        const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
+        load_residual(rr[m], p.res + rvox * COUT + cbase);
+      }
+    }
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
       const int yo = ty0 + wave * TM + m;
       if (yo >= p.Ho || xo >= p.Wo) continue;
       if ((DSM_ONCE_OFF & 4) && p.B != 12345) continue;
       const long vox = (((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo;
-      const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
-      store_tile<COUT>(acc[m][n], af, p.relu, p.y + vox * COUT + cbase,
-                       p.res ? p.res + rvox * COUT + cbase : nullptr, am);
+      store_tile<COUT>(acc[m][n], af, p.relu, p.y + vox * COUT + cbase, rr[m], p.res != nullptr, am);
     }
   }
   flush_amax(p.y_amax, am, reinterpret_cast<float*>(lds_raw));
+}
+
+// ----------------------------------------------------------------------------
+// The stride-2 3x3x3 convolution with two kinds of waves: conv_s2_kernel (fp16 modes).
+// conv_split_kernel<S = 2> requests a chunk (one z-tap plane x 16 channels: ~0.7 us of MFMAs) one
+// chunk ahead -- less than a memory latency -- and its waves wait for vector memory in order, weights
+// behind activations behind stores: MFMA pipe busy 19 %, 85-111 us per launch for 24 us of MFMAs
+// (profiles/r03_a_pmc.md).  Same cure as conv_zs.hpp: 512 threads, four MFMA waves (weight ring, LDS
+// fragment reads, MFMAs, the tile's epilogue) and four staging waves that keep D = 4 chunks of
+// activation loads in flight in their own registers, split one chunk per iteration into the other LDS
+// image and never touch a weight.  Image layout, weight layout, tile walk and results are
+// conv_split_kernel<PM, 2, 1, 3, 1, 2>'s.
+// ----------------------------------------------------------------------------
+template <int PM>
+__global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p) {
+  constexpr int NT = 2, TM = 1, KZ = 3, S = 2;
+  using C = ConvSplitCfg<PM, NT, TM, KZ, 1, S, 1>;
+  using frag = typename Prec<PM>::frag;
+  constexpr int NP = C::NP, NPW = C::NPW, TY = C::TY, CK = C::CK, IX = C::IX, NE = C::NE,
+                NPF = C::NPF, PITCH = C::PITCH, RP = C::RP, IMG = C::IMG, COUT = C::COUT;
+  constexpr int NITEM = 9, AHEAD = 3;
+  constexpr int D = 4;                          // chunks of activation loads in flight
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool staging = wave >= 4;               // wave-uniform role
+  const int stid = tid & 255;
+  const int nch = p.Cin / CK;
+  int step, end;
+  const int t0 = first_tile(p.ntiles, step, end);
+  if (t0 >= end) return;
+  const int nchunks = ((end - t0 + step - 1) / step) * KZ * nch;     // this workgroup's chunks
+  const SplitScale ss = split_scale<PM>(p);
+
+  struct Pos { int t, dz, ck, yb, xb, z; unsigned base; };
+  auto tile_pos = [&](int id) {
+    Pos q; q.t = id; q.dz = 0; q.ck = 0;
+    q.xb = (id % p.ntx) * 32 * S - 1; id /= p.ntx;
+    q.yb = (id % p.nty) * TY * S - 1; id /= p.nty;
+    q.z = (id % p.Do) * S; const int b = id / p.Do;
+    q.base = (unsigned)(4l * (((((long)b * p.Di + q.z) * p.Hi + q.yb) * p.Wi + q.xb) * p.Cin));
+    return q;
+  };
+  auto advance = [&](Pos q) {                   // next chunk: ck fastest, then dz, then the tile
+    if (++q.ck == nch) { q.ck = 0; if (++q.dz == KZ) q = tile_pos(q.t + step); }
+    return q;
+  };
+  float* const aff = reinterpret_cast<float*>(lds_raw + 2 * IMG);
+  if (tid < NTHREADS) stage_affine_lds(aff, p.scale, p.shift, COUT, tid, ss.out);   // visible after the first barrier
+  float am = 0.f;
+
+  if (staging) {
+    // ===================================================================== staging waves
+    f32x4 pf[D][NPF];
+    unsigned goff[NPF], yx[NPF], voff[NPF];
+    int wofs[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      const int e = stid + k * NTHREADS;
+      const int v = e / 4, q = e % 4;
+      const int yy = v / IX, xx = v % IX;
+      goff[k] = 4u * (unsigned)((yy * p.Wi + xx) * p.Cin + 4 * q);
+      yx[k] = e < NE ? ((unsigned)yy << 16 | (unsigned)xx) : 0x7fff0000u;   // tail: never in range
+      const int ec = min(e, NE - 1);
+      const int vc = ec / 4, yc = vc / IX, xc = vc % IX;
+      wofs[k] = (e < NE) ? (yc * RP + (xc & 1) * 33 + (xc >> 1)) * PITCH + (ec % 4) * 8
+                         : (C::IY * RP) * PITCH + (stid & 3) * 8;           // the tail: spare voxels behind the image
+    }
+    const unsigned plane_bytes = 4u * (unsigned)p.Hi * (unsigned)p.Wi * (unsigned)p.Cin;
+    constexpr unsigned OOBV = 0x80000000u;
+    auto tile_offsets = [&](const Pos& q) {
+#pragma unroll
+      for (int k = 0; k < NPF; ++k) {
+        const int y = q.yb + (int)(yx[k] >> 16), x = q.xb + (int)(yx[k] & 0xffffu);
+        const bool ok = (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+        voff[k] = ok ? q.base + goff[k] : OOBV;
+      }
+    };
+    auto load_chunk = [&](auto setc, const Pos& q, bool valid) {
+      constexpr int set = decltype(setc)::value;
+      const int zin = q.z + q.dz - 1;
+      const bool live = valid && zin >= 0 && zin < p.Di;
+      const long off = (long)(q.dz - 1) * (long)plane_bytes + (long)q.ck * (CK * 4);
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const char*>(p.x) + off, live ? p.xbytes : 0u);
+#pragma unroll
+      for (int k = 0; k < NPF; ++k) pf[set][k] = buffer_load16(rs, voff[k], 0);
+    };
+    auto split_chunk = [&](auto setc, unsigned char* img) {
+      constexpr int set = decltype(setc)::value;
+#pragma unroll
+      for (int k = 0; k < NPF; ++k) {
+        unsigned lo[NP], hi[NP];
+        split_pair<PM>(pf[set][k].x, pf[set][k].y, ss.sx, lo);
+        split_pair<PM>(pf[set][k].z, pf[set][k].w, ss.sx, hi);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          u32x2 v; v.x = lo[q]; v.y = hi[q];
+          *reinterpret_cast<u32x2*>(img + wofs[k] + q * 32) = v;
+        }
+      }
+    };
+    // chunk k waits in register set k % D from its request (iteration k - D) to its split (k - 1)
+    Pos lead = tile_pos(t0);                    // the chunk requested last
+    int nlead = 0;                              // its index
+    tile_offsets(lead);
+    load_chunk(std::integral_constant<int, 0>{}, lead, true);
+    split_chunk(std::integral_constant<int, 0>{}, lds_raw);
+    static_for<1, D>([&](auto kc) {
+      const Pos nx = advance(lead);
+      ++nlead;
+      if (nlead < nchunks && nx.dz == 0 && nx.ck == 0) tile_offsets(nx);
+      lead = nx;
+      load_chunk(kc, lead, nlead < nchunks);
+    });
+    int i = 0;
+    __syncthreads();                            // image 0 is complete
+    // iteration i (P = i % D): chunk i is on the MFMA waves; request chunk i + D into the set chunk i
+    // left, split chunk i + 1 (requested D - 1 iterations ago) into the other image
+    auto iteration = [&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      const Pos nx = advance(lead);
+      ++nlead;
+      if (nlead < nchunks && nx.dz == 0 && nx.ck == 0) tile_offsets(nx);
+      lead = nx;
+      load_chunk(pc, lead, nlead < nchunks);
+      if (i + 1 < nchunks) split_chunk(std::integral_constant<int, (P + 1) % D>{}, lds_raw + ((i + 1) & 1) * IMG);
+      __syncthreads();                          // chunk i done; image (i + 1) & 1 complete
+      ++i;
+      return i >= nchunks;
+    };
+    while (true) {
+      if (iteration(std::integral_constant<int, 0>{})) break;
+      if (iteration(std::integral_constant<int, 1>{})) break;
+      if (iteration(std::integral_constant<int, 2>{})) break;
+      if (iteration(std::integral_constant<int, 3>{})) break;
+    }
+  } else {
+    // ===================================================================== MFMA waves
+    const int r = lane & 31, h = lane >> 5;
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.wbytes);
+    auto wbase_of = [&](const Pos& q) { return (unsigned)((q.ck * KZ + q.dz) * 9) * (NT * NPW * 64 * 16); };
+    const int rd_off = ((wave * TM * S) * RP + r) * PITCH + h * 16;
+    f32x16 acc[NT];
+    const unsigned lane16 = lane * 16u;
+    static_assert(NITEM % AHEAD == 0, "continuous weight ring");
+    frag wq[AHEAD][NT][NP];
+    auto wload = [&](auto ic, unsigned wb) {
+      constexpr int item = decltype(ic)::value;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+          wq[item % AHEAD][n][q] = __builtin_bit_cast(
+              frag, buffer_load16(wrsrc, lane16, wb + ((item * NT + n) * NPW + q) * (64 * 16)));
+    };
+    Pos cur_pos = tile_pos(t0);
+    static_for<0, AHEAD - 1>([&](auto ic) { wload(ic, wbase_of(cur_pos)); });
+    int i = 0;
+    __syncthreads();                            // image 0 is complete
+    while (true) {
+      const unsigned char* const rd = lds_raw + (i & 1) * IMG + rd_off;
+      const Pos nxt = advance(cur_pos);
+      if (cur_pos.dz == 0 && cur_pos.ck == 0) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[n][k] = 0.f;
+      }
+      const unsigned wchunk = wbase_of(cur_pos), wnext = i + 1 < nchunks ? wbase_of(nxt) : wbase_of(cur_pos);
+      frag xq[2][NP];
+      auto xload = [&](auto sc) {
+        constexpr int item = decltype(sc)::value;
+        constexpr int dy = item / 3, dx = item % 3;
+        constexpr int vo = dy * RP + (dx & 1) * 33 + (dx >> 1);
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+          xq[item & 1][q] = *reinterpret_cast<const frag*>(rd + vo * PITCH + q * 32);
+      };
+      xload(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, NITEM>([&](auto ic) {
+        constexpr int item = decltype(ic)::value;
+        if constexpr (item + AHEAD - 1 < NITEM) wload(std::integral_constant<int, item + AHEAD - 1>{}, wchunk);
+        else wload(std::integral_constant<int, item + AHEAD - 1 - NITEM>{}, wnext);
+        if constexpr (item + 1 < NITEM) xload(std::integral_constant<int, item + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) mma32<PM>(acc[n], wq[item % AHEAD][n], xq[item & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if (cur_pos.dz == KZ - 1 && cur_pos.ck == nch - 1) {     // epilogue of the tile
+        int id = cur_pos.t;
+        const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
+        const int ty0 = (id % p.nty) * TY; id /= p.nty;
+        const int tz = id % p.Do, tb = id / p.Do;
+        const int xo = tx0 + r, yo = ty0 + wave;
+        if (yo < p.Ho && xo < p.Wo) {
+          const long vox = (((long)tb * p.Do + tz) * p.Ho + yo) * p.Wo + xo;
+          const long rvox = (((long)tb * p.Dr + tz) * p.Hr + yo) * p.Wr + xo;
+          Residual rr[NT];
+          if (p.res) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) load_residual(rr[n], p.res + rvox * COUT + n * 32 + 4 * h);
+          }
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const int cbase = n * 32 + 4 * h;
+            const Affine af = load_affine_lds(aff, COUT, cbase);
+            store_tile<COUT>(acc[n], af, p.relu, p.y + vox * COUT + cbase, rr[n], p.res != nullptr, am);
+          }
+        }
+      }
+      __syncthreads();                          // chunk i done
+      cur_pos = nxt; ++i;
+      if (i >= nchunks) break;
+    }
+  }
+  flush_amax8(p.y_amax, am, reinterpret_cast<float*>(lds_raw));
 }
 
 // ----------------------------------------------------------------------------
@@ -825,18 +1065,34 @@ __global__ __launch_bounds__(NTHREADS, (DeconvSplitCfg<PM, NT>::WGS)) void decon
       const int zo = 2 * cur_pos.m + cur_pos.pz;
       const int ym = cur_pos.yb + wave, xm_ = cur_pos.xb + r;  // this lane's input-grid position
       if (zo < p.Do && ym < p.Hi && xm_ < p.Wi) {
+        // the skip values of CB classes first, then their stores (conv_common.hpp, load_residual); CB = all
+        // four where the registers allow (NT = 1)
+        constexpr int CB = NT == 1 ? 4 : 2;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const int cbase = n * 32 + 4 * h;
           const Affine af = load_affine_lds(aff, COUT, cbase);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int yo = 2 * ym + (c >> 1), xo = 2 * xm_ + (c & 1);
-            if (yo >= p.Ho || xo >= p.Wo) continue;
-            const long vox = (((long)cur_pos.b * p.Do + zo) * p.Ho + yo) * p.Wo + xo;
-            const long rvox = (((long)cur_pos.b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo;
-            store_tile<COUT>(acc[c][n], af, p.relu, p.y + vox * COUT + cbase,
-                             p.res ? p.res + rvox * COUT + cbase : nullptr, am);
+          for (int c0 = 0; c0 < 4; c0 += CB) {
+            Residual rr[CB];
+            if (p.res) {
+#pragma unroll
+              for (int ci = 0; ci < CB; ++ci) {
+                const int c = c0 + ci;
+                const int yo = 2 * ym + (c >> 1), xo = 2 * xm_ + (c & 1);
+                if (yo >= p.Ho || xo >= p.Wo) continue;
+                const long rvox = (((long)cur_pos.b * p.Dr + zo) * p.Hr + yo) * p.Wr + xo;
+                load_residual(rr[ci], p.res + rvox * COUT + cbase);
+              }
+            }
+#pragma unroll
+            for (int ci = 0; ci < CB; ++ci) {
+              const int c = c0 + ci;
+              const int yo = 2 * ym + (c >> 1), xo = 2 * xm_ + (c & 1);
+              if (yo >= p.Ho || xo >= p.Wo) continue;
+              const long vox = (((long)cur_pos.b * p.Do + zo) * p.Ho + yo) * p.Wo + xo;
+              store_tile<COUT>(acc[c][n], af, p.relu, p.y + vox * COUT + cbase, rr[ci], p.res != nullptr, am);
+            }
           }
         }
       }
@@ -912,6 +1168,26 @@ int run_conv_once(ConvParams p, hipStream_t s) {
   return dsm_launch_status();
 }
 
+template <int PM>
+int run_conv_s2(ConvParams p, hipStream_t s) {
+  using C = ConvSplitCfg<PM, 2, 1, 3, 1, 2, 1>;
+  p.ntx = dsm_cdiv(p.Wo, 32); p.nty = dsm_cdiv(p.Ho, C::TY);
+  const long nt = (long)p.B * p.Do * p.nty * p.ntx;
+  if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
+  p.ntiles = (int)nt;
+  static thread_local bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute((const void*)conv_s2_kernel<PM>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
+      return DSM_ERR_LAUNCH;
+    configured = true;
+  }
+  int blocks = p.force_blocks ? p.force_blocks : 256;          // one workgroup per CU
+  if (blocks > p.ntiles) blocks = p.ntiles;
+  if (blocks >= 8) blocks &= ~7;                               // whole rounds over the 8 XCDs
+  hipLaunchKernelGGL(conv_s2_kernel<PM>, dim3(blocks), dim3(512), C::LDS, s, p);
+  return dsm_launch_status();
+}
+
 template <int PM, int NT>
 int run_deconv_split(ConvParams p, hipStream_t s) {
   using C = DeconvSplitCfg<PM, NT>;
@@ -927,7 +1203,10 @@ template <int PM>
 int dispatch_split(const Plan& pl, const ConvParams& p, hipStream_t s) {
   if (pl.kind == 6) return pl.NT == 1 ? run_deconv_split<PM, 1>(p, s) : run_deconv_split<PM, 2>(p, s);
   if (pl.kind != 5) return DSM_ERR_UNSUPPORTED;
-  if (pl.S == 2) return run_conv_split<PM, 2, 1, 3, 1, 2>(p, s);
+  if (pl.S == 2) {
+    if constexpr (PM != 3) { if (!p.single_kind) return run_conv_s2<PM>(p, s); }
+    return run_conv_split<PM, 2, 1, 3, 1, 2>(p, s);
+  }
   if constexpr (PM != 3) {                      // (bf16x3's three-plane images do not leave room)
     if (pl.once) {                              // one round of tiles, every chunk requested up front
       if (pl.KZ == 1 && pl.NT == 1 && pl.TM == 2 && pl.DIL == 1 && pl.nsplit == 2 && p.Cin == 64)

@@ -186,7 +186,7 @@ typedef struct dsm_conv3d_args {
 #define DSM_CONV_FP32_MFMA      0x1      /* keep the layer on the exact fp32-input MFMA (no bf16x3)   */
 #define DSM_CONV_COUT1_CHUNKED  0x2      /* Cout = 1: the chunked kernel instead of the z-sliding one */
 #define DSM_CONV_NO_NSPLIT      0x4      /* 2-D bf16x3 layers: one workgroup per tile (no N-split)    */
-#define DSM_CONV_NO_ONCE        0x8      /* 2-D 64 -> 64 layers: the chunk-pipelined kernel, not the single-tile form */
+#define DSM_CONV_NO_ONCE        0x8      /* A/B: the chunk-pipelined single-kind kernels instead of the single-tile (2-D 64 -> 64) and two-kind (stride-2 3-D) forms */
 #define DSM_CONV_TM_SHIFT       4        /* bits 4..7: force the tile height 4*TM rows (TM = 1, 2, 4) */
 #define DSM_CONV_BLOCKS_SHIFT   16       /* bits 16..31: force the persistent grid size               */
 

@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--modes", default="bf16x3,f16x2,f16")
 ap.add_argument("--rep", type=int, default=30)
 ap.add_argument("--only", default="")
+ap.add_argument("--res", action="store_true", help="with a skip tensor of the output's shape (residual add in the epilogue)")
 ap.add_argument("--graph", action="store_true", help="REP launches captured into one hipGraph and replayed: GPU time per launch (small kernels are host-bound when launched eagerly)")
 ap.add_argument("--flags", default="0,%d" % _lib.DSM_CONV_NO_NSPLIT, help="conv_flags variants, e.g. 0,4,16 (16 = 4-row tiles)")
 args = ap.parse_args()
@@ -72,18 +73,22 @@ for name, kind, cin, cout, stride, tr, dil, shape in LAYERS:
         x = x.contiguous(memory_format=torch.channels_last)
         w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
         packed = cv.pack_conv2d_weight(w)
-        run = lambda: cv.conv2d_block(x, packed, cout, relu=1, dilation=dil)
+        run = lambda res=None: cv.conv2d_block(x, packed, cout, residual=res, relu=1, dilation=dil)
     else:
         x = x.contiguous(memory_format=torch.channels_last_3d)
         w = torch.randn(*((cin, cout) if tr else (cout, cin)), 3, 3, 3, device="cuda") * 0.05
         packed = cv.pack_conv3d_weight(w, tr)
-        run = lambda: cv.conv3d_block(x, packed, cout, stride=stride, transposed=tr, relu=1)
+        run = lambda res=None: cv.conv3d_block(x, packed, cout, residual=res, stride=stride, transposed=tr, relu=1)
     row = "%-30s" % name
     for mode, flags, _ in variants:
         o1, o2 = cv.set_option("conv_precision", mode), cv.set_option("conv_flags", flags)
         with cv.amax_scope(x.device):
             if cv.needs_amax():
                 cv.absmax(x)
-            row += "%16.1f" % bench(run, args.rep)
+            fn = run
+            if args.res:
+                skip = torch.randn_like(run())
+                fn = lambda: run(skip)
+            row += "%16.1f" % bench(fn, args.rep)
         cv.set_option("conv_precision", o1), cv.set_option("conv_flags", o2)
     print(row, flush=True)

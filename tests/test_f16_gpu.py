@@ -229,3 +229,29 @@ def test_gcnet_golden_in_f16x2(cv, golden_e2e):
     with precision(cv, "f16x2"), torch.no_grad():
         out = m(imL.cuda(), imR.cuda())[1][0]
     golden_e2e.compare("e2e.gcnet.disp", out, 1e-3)
+
+
+@pytest.mark.parametrize("hw,res", [((96, 320), False), ((90, 300), True), ((93, 289), True)])   # 240 tiles of 8 x 32: one round
+@pytest.mark.parametrize("mode", ["f16x2", "f16"])
+def test_single_tile_form_of_the_64_channel_layers_gives_the_same_bits(cv, mode, hw, res):
+    """One round of tiles: the towers' Conv2d(64, 64, 3) layers (submodule.py:24-46,108-118) run the
+    single-tile kernel (every chunk of the tile requested up front); it computes the same products in
+    the same order as the chunk-pipelined kernel it replaces there (`DSM_CONV_NO_ONCE`)."""
+    from dsmnet_amd import _lib
+    H, W = hw
+    x = relu_like(81, 2, 64, H, W)
+    w = seeded(82, 64, 64, 3, 3, scale=(2.0 / (9 * 64)) ** 0.5)
+    sc, sh = seeded(83, 64).abs() + 0.5, seeded(84, 64)
+    r = seeded(85, 2, 64, H, W).cuda() if res else None
+    xs = x.cuda().contiguous(memory_format=torch.channels_last)
+    packed = cv.pack_conv2d_weight(w.cuda())
+    outs = []
+    with precision(cv, mode):
+        assert plan_of(cv, x, 64, 1, False, kd=1, dil=1, mode=mode).endswith(",once")
+        for flags in (0, _lib.DSM_CONV_NO_ONCE):
+            old = cv.set_option("conv_flags", flags)
+            try:
+                outs.append(cv.conv2d_block(xs, packed, 64, sc.cuda(), sh.cuda(), r, relu=1))
+            finally:
+                cv.set_option("conv_flags", old)
+    assert torch.equal(outs[0], outs[1])
