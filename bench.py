@@ -70,7 +70,7 @@ def synthetic_pair(seed, device):
 
 def stage_of(kernel):
     """Forward stage a kernel of this library belongs to (per-stage timing)."""
-    if kernel.startswith(("conv2d", "spp_")):
+    if kernel.startswith(("conv2d", "spp_", "basicblock2d")):
         return "towers"
     if kernel.startswith("volume"):
         return "volume"

@@ -47,6 +47,14 @@ class Conv3dArgs(ctypes.Structure):
                 ("vol_virtual", c_int), ("vol_mask_left", c_int)]
 
 
+class BasicBlock2dArgs(ctypes.Structure):
+    """struct dsm_basicblock2d_args (include/dsmnet_hip.h)."""
+    _fields_ = [("x", c_void_p), ("y", c_void_p), ("w1_packed", c_void_p), ("w2_packed", c_void_p),
+                ("scale1", c_void_p), ("shift1", c_void_p), ("scale2", c_void_p), ("shift2", c_void_p),
+                ("x_amax", c_void_p), ("y_amax", c_void_p),
+                ("B", c_int), ("H", c_int), ("W", c_int), ("C", c_int), ("precision", c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in dsmnet_hip.h
 SIGNATURES = {
     "dsm_abi_version": (c_int, []),
@@ -62,6 +70,7 @@ SIGNATURES = {
     "dsm_conv_pack_weights": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "dsm_absmax": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "dsm_conv3d_fwd": (c_int, [ctypes.POINTER(Conv3dArgs), c_void_p]),
+    "dsm_basicblock2d_fwd": (c_int, [ctypes.POINTER(BasicBlock2dArgs), c_void_p]),
     "dsm_conv3d_plan": (c_int, [ctypes.POINTER(Conv3dArgs), ctypes.c_char_p, c_int]),
     "dsm_conv3d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_void_p] * 3),
     "dsm_conv2d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p] * 3),
@@ -115,7 +124,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.dsm_abi_version() != 6:
+    if lib.dsm_abi_version() != 7:
         raise DsmnetHipError("libdsmnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -164,6 +164,25 @@ def run_conv2d(folded, conv, bn, x, residual=None, relu=False):
     return F.relu(y) if relu else y
 
 
+def run_basicblock(cb1, cb2, x, downsample):
+    """``cb2(cb1(x, relu=True), residual=x)`` of a BasicBlock (models/psmnet/submodule.py:24-46) as ONE
+    launch where ``costvolume.basicblock2d`` covers it -- eval mode on the GPU, no gradient, stride-1
+    64-channel 3x3 convolutions with BatchNorm, no downsample branch -- else None (the caller runs the
+    two layers)."""
+    if downsample is not None or not isinstance(cb1, ConvBN2d) or not isinstance(cb2, ConvBN2d):
+        return None
+    c1, b1, c2, b2 = cb1[0], cb1[1], cb2[0], cb2[1]
+    if c1.training or b1.training or b2.training or torch.is_grad_enabled():
+        return None
+    if not (fused_ok(c1, x) and c1.kernel_size[0] == 3 and c2.kernel_size[0] == 3 and c2.stride[0] == 1 and
+            c2.dilation[0] == 1 and c2.in_channels == 64 and c2.out_channels == 64 and
+            cv.basicblock2d_ok(x, c1.in_channels, c1.out_channels, c1.stride[0], c1.dilation[0])):
+        return None
+    p1, s1, h1 = cb1._folded.get(c1, b1, x.shape[1])
+    p2, s2, h2 = cb2._folded.get(c2, b2, 64)
+    return cv.basicblock2d(x, p1, s1, h1, p2, s2, h2)
+
+
 class ConvBN2d(nn.Sequential):
     """``convbn``'s Sequential(Conv2d, BatchNorm2d); ``forward(x)`` equals it."""
 

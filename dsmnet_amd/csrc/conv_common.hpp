@@ -50,6 +50,19 @@ struct ZsParams {
 __attribute__((visibility("hidden"))) int run_split_f16(const Plan& pl, const ConvParams& p, hipStream_t s);
 __attribute__((visibility("hidden"))) int run_zs_f16(int pm, const ZsParams& p, int grid, hipStream_t s);
 
+// the fused 64-channel BasicBlock (basicblock2d.hpp)
+struct BbParams {
+  const float* x; float* y;
+  const unsigned char* w1; const unsigned char* w2;       // fp16 planes [Cin/16][tap9][n 2][plane][lane][16 B]
+  const float* w1_amax; const float* w2_amax;
+  const float* scale1; const float* shift1; const float* scale2; const float* shift2;
+  const float* x_amax; float* y_amax;
+  int B, H, W, ntx, nty, ntiles;
+  unsigned xbytes, wbytes;
+};
+
+__attribute__((visibility("hidden"))) int run_basicblock_f16(int pm, const BbParams& p, hipStream_t s);
+
 }  // namespace dsmk
 
 namespace {
@@ -57,6 +70,7 @@ namespace {
 using dsmk::ConvParams;
 using dsmk::Plan;
 using dsmk::ZsParams;
+using dsmk::BbParams;
 
 // Compile-time loop: f(integral_constant<int, I>) for I in [I0, N).  Used where an index must
 // be a constant expression so that accumulator arrays stay in registers (a runtime-indexed

@@ -13,6 +13,7 @@
 namespace {
 #include "conv_split.hpp"
 #include "conv_zs.hpp"
+#include "basicblock2d.hpp"
 }  // namespace
 
 int dsmk::run_zs_f16(int pm, const ZsParams& p, int grid, hipStream_t s) {
@@ -24,5 +25,11 @@ int dsmk::run_zs_f16(int pm, const ZsParams& p, int grid, hipStream_t s) {
 int dsmk::run_split_f16(const Plan& pl, const ConvParams& p, hipStream_t s) {
   if (pl.pm == 2) return dispatch_split<2>(pl, p, s);
   if (pl.pm == 1) return dispatch_split<1>(pl, p, s);
+  return DSM_ERR_UNSUPPORTED;
+}
+
+int dsmk::run_basicblock_f16(int pm, const BbParams& p, hipStream_t s) {
+  if (pm == 2) return launch_basicblock2d<2>(p, s);
+  if (pm == 1) return launch_basicblock2d<1>(p, s);
   return DSM_ERR_UNSUPPORTED;
 }

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import blocks2d
 from ... import costvolume as cv
 from ...blocks2d import ConvBN2d, _Folded2d, run_conv2d, stage_image_nhwc16
 from ...blocks3d import ConvBN3d, _versions
@@ -48,6 +49,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        fused = blocks2d.run_basicblock(self.conv1[0], self.conv2, x, self.downsample)
+        if fused is not None:                              # both convolutions in one launch (eval, 64 channels)
+            return fused
         y = self.conv1[0](x, relu=True)                    # convbn + the Sequential's ReLU
         skip = x if self.downsample is None else self.downsample(x)
         return self.conv2(y, residual=skip)                # convbn + skip add, no ReLU after

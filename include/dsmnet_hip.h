@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DSM_ABI_VERSION 6
+#define DSM_ABI_VERSION 7
 
 #define DSM_OK               0
 #define DSM_ERR_ARG         -1   /* null pointer, non-positive size, bad enum      */
@@ -209,6 +209,23 @@ int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, int 
 /* (ABI v6) max |x| over n floats, folded into *amax (atomic maximum on the float bits; the caller
  * zeroes it first): the `x_amax` of a tensor no launch of this library produced. */
 int dsm_absmax(const void* x, size_t n, float* amax, dsm_stream_t stream);
+
+/* Two convolutions per launch: the stride-1 64-channel BasicBlock of PSMNet's towers
+ * (models/psmnet/submodule.py:24-46):  y = BN2(conv2(ReLU(BN1(conv1(x))))) + x,  both Conv2d(64, 64, 3,
+ * stride 1, pad 1), folded BatchNorm as scale / shift per channel (NULL: 1 / 0).  x, y: fp32 NHWC
+ * (B, H, W, 64); w1_packed, w2_packed: dsm_conv_pack_weights buffers of the two layers (Cin = Cout = 64,
+ * kd = 1, k = 3).  precision: DSM_PREC_F16X2 or DSM_PREC_F16 (the fp16 modes only); x_amax as in
+ * dsm_conv3d_args (required), y_amax optional.  The intermediate map never leaves the chip; it is scaled
+ * for its fp16 split by each tile's own maximum.  Eval mode only (no backward). */
+typedef struct {
+  const void* x; void* y;
+  const void* w1_packed; const void* w2_packed;
+  const float* scale1; const float* shift1; const float* scale2; const float* shift2;
+  const float* x_amax; float* y_amax;
+  int B, H, W, C;
+  int precision;
+} dsm_basicblock2d_args;
+int dsm_basicblock2d_fwd(const dsm_basicblock2d_args* a, dsm_stream_t stream);
 
 int dsm_conv3d_fwd(const dsm_conv3d_args* args, dsm_stream_t stream);
 

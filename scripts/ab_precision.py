@@ -20,6 +20,7 @@ args = ap.parse_args()
 LAYERS = [
     ("2d 32->32 192x640 x8", "2d", 32, 32, 1, False, 1, (2, 192, 640)),
     ("2d 64->64 96x320 x31", "2d", 64, 64, 1, False, 1, (2, 96, 320)),
+    ("bb 64->64->64 96x320 x15", "bb", 64, 64, 1, False, 1, (2, 96, 320)),
     ("2d 128->128 96x320 x7", "2d", 128, 128, 1, False, 1, (2, 96, 320)),
     ("2d 128->128 dil2 x6", "2d", 128, 128, 1, False, 2, (2, 96, 320)),
     ("2d 320->128 lastconv", "2d", 320, 128, 1, False, 1, (2, 96, 320)),
@@ -69,7 +70,14 @@ for name, kind, cin, cout, stride, tr, dil, shape in LAYERS:
         continue
     torch.manual_seed(0)
     x = torch.randn(shape[0], cin, *shape[1:], device="cuda").relu()
-    if kind == "2d":
+    if kind == "bb":
+        if "f16" not in args.modes:
+            continue
+        x = x.contiguous(memory_format=torch.channels_last)
+        w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+        packed, packed2 = cv.pack_conv2d_weight(w), cv.pack_conv2d_weight(w.flip(0))
+        run = lambda res=None: cv.basicblock2d(x, packed, None, None, packed2, None, None)
+    elif kind == "2d":
         x = x.contiguous(memory_format=torch.channels_last)
         w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
         packed = cv.pack_conv2d_weight(w)
@@ -81,6 +89,9 @@ for name, kind, cin, cout, stride, tr, dil, shape in LAYERS:
         run = lambda res=None: cv.conv3d_block(x, packed, cout, residual=res, stride=stride, transposed=tr, relu=1)
     row = "%-30s" % name
     for mode, flags, _ in variants:
+        if kind == "bb" and mode not in ("f16x2", "f16"):
+            row += "%16s" % "-"
+            continue
         o1, o2 = cv.set_option("conv_precision", mode), cv.set_option("conv_flags", flags)
         with cv.amax_scope(x.device):
             if cv.needs_amax():

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(raw, name), "missing export: " + name
-    assert hip_lib.dsm_abi_version() == 6
+    assert hip_lib.dsm_abi_version() == 7
     assert hip_lib.dsm_strerror(0) == b"ok"
     assert b"not supported" in hip_lib.dsm_strerror(-2)
 
