@@ -30,7 +30,7 @@ def main(dirs):
     print("| kernel | " + " | ".join(counters) + " |")
     print("|---|" + "---|" * len(counters))
     for k in sorted(table):
-        if not k.startswith(("dsm", "conv", "deconv", "volume", "soft", "corr", "absmax", "spp", "box")):
+        if not k.startswith(("dsm", "conv", "deconv", "basicblock", "volume", "soft", "corr", "absmax", "spp", "box")):
             continue
         cells = []
         for c in counters:

@@ -10,7 +10,7 @@ tag, stats_csv, bench_json, prof_json = sys.argv[1:5]
 bench = json.load(open(bench_json))
 prof = json.load(open(prof_json))
 rows = list(csv.DictReader(open(stats_csv)))
-OURS = ("conv3d_mfma", "conv_split", "deconv_split", "conv_zs", "deconv3d", "cout1", "soft_argmin", "volume_", "pack_weights", "absmax", "spp_", "corr1d", "box_filter", "warp_", "stage_pair", "decoder_cat", "bn_")
+OURS = ("conv3d_mfma", "conv_split", "conv_once", "conv_s2", "basicblock2d", "deconv_split", "conv_zs", "deconv3d", "cout1", "soft_argmin", "volume_", "pack_weights", "absmax", "spp_", "corr1d", "box_filter", "warp_", "stage_pair", "decoder_cat", "bn_")
 
 
 def short(n):
@@ -41,6 +41,15 @@ def plan_name(n):
             return "conv3d_%s_mfma_kernel<S=2,NT=%d,TM=%d>" % (pr, NT, TM)
         return ("conv3d_%s_mfma_kernel<NT=%d,TM=%d>" % (pr, NT, TM) if KZ == 3 else
                 "conv2d_%s_mfma_kernel<NT=%d,TM=%d,DIL=%d>" % (pr, NT, TM, DIL))
+    m = re.match(r"basicblock2d_kernel<(\d+)>", n)
+    if m:
+        return "basicblock2d_%s_mfma_kernel" % PR[m.group(1)]
+    m = re.match(r"conv_once_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", n)
+    if m:
+        return "conv2d_%s_mfma_kernel<NT=%s,TM=%s,DIL=1>x%s,once" % (PR[m.group(1)], m.group(2), m.group(3), m.group(5))
+    m = re.match(r"conv_s2_kernel<(\d+)>", n)
+    if m:
+        return "conv3d_%s_mfma_kernel<S=2,NT=2,TM=1>" % PR[m.group(1)]
     m = re.match(r"deconv_split_kernel<(\d+), (\d+)>", n)
     if m:
         return "deconv3d_%s_mfma_kernel<NT=%s>" % (PR[m.group(1)], m.group(2))
