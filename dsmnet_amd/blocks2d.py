@@ -174,7 +174,7 @@ def run_basicblock(cb1, cb2, x, downsample):
     c1, b1, c2, b2 = cb1[0], cb1[1], cb2[0], cb2[1]
     if c1.training or b1.training or b2.training or torch.is_grad_enabled():
         return None
-    if not (fused_ok(c1, x) and c1.kernel_size[0] == 3 and c2.kernel_size[0] == 3 and c2.stride[0] == 1 and
+    if not (fused_ok(c1, x) and fused_ok(c2, x) and c1.kernel_size[0] == 3 and c2.kernel_size[0] == 3 and c2.stride[0] == 1 and
             c2.dilation[0] == 1 and c2.in_channels == 64 and c2.out_channels == 64 and
             cv.basicblock2d_ok(x, c1.in_channels, c1.out_channels, c1.stride[0], c1.dilation[0])):
         return None
