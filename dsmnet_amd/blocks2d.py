@@ -164,23 +164,28 @@ def run_conv2d(folded, conv, bn, x, residual=None, relu=False):
     return F.relu(y) if relu else y
 
 
-def run_basicblock(cb1, cb2, x, downsample):
-    """``cb2(cb1(x, relu=True), residual=x)`` of a BasicBlock (models/psmnet/submodule.py:24-46) as ONE
-    launch where ``costvolume.basicblock2d`` covers it -- eval mode on the GPU, no gradient, stride-1
-    64-channel 3x3 convolutions with BatchNorm, no downsample branch -- else None (the caller runs the
-    two layers)."""
-    if downsample is not None or not isinstance(cb1, ConvBN2d) or not isinstance(cb2, ConvBN2d):
+def run_basicblock_layers(fold1, c1, b1, fold2, c2, b2, x, relu_after):
+    """``bn2(conv2(relu(bn1(conv1(x))))) + x`` (``relu_after``: ReLU after the add) as ONE launch where
+    ``costvolume.basicblock2d`` covers it -- eval mode on the GPU, no gradient, two stride-1 3x3
+    convolutions of 32 or 64 channels, each with its BatchNorm -- else None (the caller runs the two
+    layers)."""
+    if b1 is None or b2 is None or c1.training or b1.training or b2.training or torch.is_grad_enabled():
         return None
-    c1, b1, c2, b2 = cb1[0], cb1[1], cb2[0], cb2[1]
-    if c1.training or b1.training or b2.training or torch.is_grad_enabled():
-        return None
-    if not (fused_ok(c1, x) and fused_ok(c2, x) and c1.kernel_size[0] == 3 and c2.kernel_size[0] == 3 and c2.stride[0] == 1 and
-            c2.dilation[0] == 1 and c2.in_channels == 64 and c2.out_channels == 64 and
+    if not (fused_ok(c1, x) and fused_ok(c2, x) and c1.kernel_size[0] == 3 and c2.kernel_size[0] == 3 and
+            c2.stride[0] == 1 and c2.dilation[0] == 1 and c2.in_channels == c2.out_channels == c1.out_channels and
             cv.basicblock2d_ok(x, c1.in_channels, c1.out_channels, c1.stride[0], c1.dilation[0])):
         return None
-    p1, s1, h1 = cb1._folded.get(c1, b1, x.shape[1])
-    p2, s2, h2 = cb2._folded.get(c2, b2, 64)
-    return cv.basicblock2d(x, p1, s1, h1, p2, s2, h2)
+    p1, s1, h1 = fold1.get(c1, b1, x.shape[1])
+    p2, s2, h2 = fold2.get(c2, b2, x.shape[1])
+    return cv.basicblock2d(x, p1, s1, h1, p2, s2, h2, relu=relu_after)
+
+
+def run_basicblock(cb1, cb2, x, downsample):
+    """PSMNet's BasicBlock (models/psmnet/submodule.py:24-46): ``cb2(cb1(x, relu=True), residual=x)`` in one
+    launch, or None."""
+    if downsample is not None or not isinstance(cb1, ConvBN2d) or not isinstance(cb2, ConvBN2d):
+        return None
+    return run_basicblock_layers(cb1._folded, cb1[0], cb1[1], cb2._folded, cb2[0], cb2[1], x, False)
 
 
 class ConvBN2d(nn.Sequential):

@@ -675,24 +675,25 @@ def conv2d_block(x, packed_weight, cout, scale=None, shift=None, residual=None, 
 def basicblock2d_ok(x, cin, cout, stride, dilation):
     """Can a BasicBlock (two 3x3 convolutions + skip add) run as ONE launch (csrc/basicblock2d.hpp)?
     The towers' stride-1 64-channel blocks in the fp16 modes, eval."""
-    return (_OPTIONS["fuse_blocks"] and _OPTIONS["conv_precision"] in ("f16x2", "f16") and cin == 64 and
-            cout == 64 and stride == 1 and dilation == 1 and x.dim() == 4 and x.shape[1] == 64 and
+    return (_OPTIONS["fuse_blocks"] and _OPTIONS["conv_precision"] in ("f16x2", "f16") and cin in (32, 64) and
+            cout == cin and stride == 1 and dilation == 1 and x.dim() == 4 and x.shape[1] == cin and
             4 * x.numel() < 2 ** 31)
 
 
-def basicblock2d(x, packed1, scale1, shift1, packed2, scale2, shift2):
-    """``conv2(relu(conv1(x) * scale1 + shift1)) * scale2 + shift2 + x`` on an NHWC map with 64
-    channels, both convolutions 3x3 / stride 1 / pad 1 (models/psmnet/submodule.py:24-46 with the
-    BatchNorms folded): one launch, the intermediate map stays in LDS.  ``packed*``: the layers'
-    ``pack_conv2d_weight`` buffers.  Inference only; fp16 modes only."""
+def basicblock2d(x, packed1, scale1, shift1, packed2, scale2, shift2, relu=False):
+    """``conv2(relu(conv1(x) * scale1 + shift1)) * scale2 + shift2 + x`` (``relu``: ReLU after the add)
+    on an NHWC map with 64 or 32 channels, both convolutions 3x3 / stride 1 / pad 1
+    (models/psmnet/submodule.py:24-46, models/util_conv.py:181-210 with the BatchNorms folded): one
+    launch, the intermediate map stays in LDS.  ``packed*``: the layers' ``pack_conv2d_weight``
+    buffers.  Inference only; fp16 modes only."""
     _require_device("basicblock2d", x, packed1, packed2, scale1, shift1, scale2, shift2)
     if not x.is_contiguous(memory_format=_CL2D):
         x = carry_amax(x.contiguous(memory_format=_CL2D), x)
     B, C, H, W = x.shape
     mode = _OPTIONS["conv_precision"]
-    if C != 64 or mode not in ("f16x2", "f16"):
-        raise ValueError("basicblock2d: 64 channels and an fp16 precision mode, got C=%d, %s" % (C, mode))
-    y = torch.empty((B, 64, H, W), device=x.device, dtype=torch.float32, memory_format=_CL2D)
+    if C not in (32, 64) or mode not in ("f16x2", "f16"):
+        raise ValueError("basicblock2d: 32 or 64 channels and an fp16 precision mode, got C=%d, %s" % (C, mode))
+    y = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32, memory_format=_CL2D)
     a = _lib.BasicBlock2dArgs()
     a.x, a.y = x.data_ptr(), y.data_ptr()
     a.w1_packed, a.w2_packed = packed1.data_ptr(), packed2.data_ptr()
@@ -700,14 +701,15 @@ def basicblock2d(x, packed1, scale1, shift1, packed2, scale2, shift2):
     a.shift1 = None if shift1 is None else shift1.data_ptr()
     a.scale2 = None if scale2 is None else scale2.data_ptr()
     a.shift2 = None if shift2 is None else shift2.data_ptr()
-    a.B, a.H, a.W, a.C = B, H, W, 64
+    a.B, a.H, a.W, a.C = B, H, W, C
+    a.relu = 1 if relu else 0
     a.precision = _lib.DSM_PREC_F16X2 if mode == "f16x2" else _lib.DSM_PREC_F16
     xa = amax_of(x)
     ya = _ARENA.slot(y.device)
     a.x_amax, a.y_amax = xa.data_ptr(), ya.data_ptr()
     y._dsm_amax = ya
-    work = 2.0 * 2 * 9 * 64 * 64 * B * H * W
-    with torch.cuda.device(x.device), _timed("basicblock2d_%s_mfma_kernel" % mode, work):
+    work = 2.0 * 2 * 9 * C * C * B * H * W
+    with torch.cuda.device(x.device), _timed("basicblock2d_%s_mfma_kernel<C=%d>" % (mode, C), work):
         rc = _lib.load().dsm_basicblock2d_fwd(ctypes.byref(a), _stream())
     _lib.check(rc, "dsm_basicblock2d_fwd")
     del xa

@@ -1,5 +1,6 @@
-// Two convolutions per launch: PSMNet's 64-channel BasicBlock (models/psmnet/submodule.py:24-46),
-//   y = BN2(conv2(ReLU(BN1(conv1(x))))) + x,        conv1, conv2 = Conv2d(64, 64, 3, stride 1, pad 1),
+// Two convolutions per launch: the stride-1 BasicBlock of PSMNet's towers (models/psmnet/submodule.py:24-46;
+// C = 64: layer2, C = 32: layer1) and of GCNet's (models/util_conv.py:181-210; C = 32, ReLU after the add),
+//   y = [ReLU](BN2(conv2(ReLU(BN1(conv1(x))))) + x),   conv1, conv2 = Conv2d(C, C, 3, stride 1, pad 1),
 // with the intermediate map kept in LDS.  Included by conv_f16.hip (fp16 modes) after conv_split.hpp.
 //
 // Why: the towers' 64-channel layers run ONE round of workgroups per launch, whose load, multiply and
@@ -32,10 +33,11 @@
 #define DSM_BB_OFF 0           // timing-only A/B builds: 1 no conv1 MFMAs, 2 no conv2 MFMAs, 4 no activation loads, 8 no stores, 16 no intermediate split
 #endif
 
-template <int PM>
+template <int PM, int C_>
 struct BbCfg {
   static constexpr int NP = Prec<PM>::NP, NPW = Prec<PM>::NPW;
-  static constexpr int C = 64, NCH = 4, NT = 2;
+  static constexpr int C = C_, NCH = C / 16, NT = C / 32;     // 64 (PSMNet layer2) or 32 (PSMNet layer1, GCNet)
+  static constexpr int MG = 8 / NT;                          // waves = NT output blocks x MG tile groups
   static constexpr int TY = 8, BY = TY + 4, BX = 36;        // input box
   static constexpr int MY = TY + 2, MX = 34, NMID = MY * MX; // intermediate box: 340 voxels
   static constexpr int NMT = (NMID + 31) / 32;               // 11 M-tiles
@@ -45,13 +47,13 @@ struct BbCfg {
   static constexpr int PITCH = 32 * NP + 16;
   static constexpr int XIMG = NPF * 128 * PITCH;             // 512 voxel slots
   static constexpr int TCH = NMT * 32 * PITCH;               // one 16-channel chunk of T (352 voxel slots)
-  static constexpr int LDS = XIMG + NCH * TCH + 4 * 64 * 4 + 64;
+  static constexpr int LDS = XIMG + NCH * TCH + 4 * C * 4 + 64;
   static_assert(LDS <= 160 * 1024, "LDS");
 };
 
-template <int PM>
+template <int PM, int C>
 __global__ __launch_bounds__(512, 1) void basicblock2d_kernel(BbParams p) {
-  using Cf = BbCfg<PM>;
+  using Cf = BbCfg<PM, C>;
   using frag = typename Prec<PM>::frag;
   constexpr int NP = Cf::NP, NPW = Cf::NPW, NCH = Cf::NCH, NT = Cf::NT, TY = Cf::TY, BX = Cf::BX, MX = Cf::MX,
                 NMID = Cf::NMID, NVOX = Cf::NVOX, NPF = Cf::NPF, PITCH = Cf::PITCH, XIMG = Cf::XIMG, TCH = Cf::TCH;
@@ -60,11 +62,12 @@ __global__ __launch_bounds__(512, 1) void basicblock2d_kernel(BbParams p) {
   unsigned char* const ximg = lds_raw;
   unsigned char* const timg = lds_raw + XIMG;
   float* const aff = reinterpret_cast<float*>(lds_raw + XIMG + NCH * TCH);   // scale1, shift1, scale2, shift2
-  float* const red = aff + 4 * 64;
+  float* const red = aff + 4 * C;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int nw = wave >> 2, mg = wave & 3;     // this wave's 32-channel output block and M-tile group
+  constexpr int MG = Cf::MG;
+  const int nw = wave / MG, mg = wave % MG;    // this wave's 32-channel output block and M-tile group
   int id = blockIdx.x;
   if (id >= p.ntiles) return;
   const int tx0 = (id % p.ntx) * 32; id /= p.ntx;
@@ -75,8 +78,8 @@ __global__ __launch_bounds__(512, 1) void basicblock2d_kernel(BbParams p) {
   const int ex = dsm_amax_exponent(*p.x_amax), ew1 = dsm_amax_exponent(*p.w1_amax), ew2 = dsm_amax_exponent(*p.w2_amax);
   const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dsm_pow2f(ex))));
   const float so1 = dsm_pow2f(-(ex + ew1));
-  if (tid < 256) {
-    const int c = tid & 63, which = tid >> 6;
+  if (tid < 4 * C) {
+    const int c = tid % C, which = tid / C;
     const float* src = which == 0 ? p.scale1 : which == 1 ? p.shift1 : which == 2 ? p.scale2 : p.shift2;
     float v = src ? src[c] : ((which & 1) ? 0.f : 1.f);
     if (which == 0) v *= so1;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(512, 1) void basicblock2d_kernel(BbParams p) {
     const int yy = v / BX, xx = v % BX;
     const int y = ty0 - 2 + yy, x = tx0 - 2 + xx;
     const bool ok = v < NVOX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-    voff[k] = ok ? (unsigned)(4l * ((((long)b * p.H + y) * p.W + x) * 64 + 4 * q)) : OOBV;
+    voff[k] = ok ? (unsigned)(4l * ((((long)b * p.H + y) * p.W + x) * C + 4 * q)) : OOBV;
   }
   f32x4 pf[NCH][NPF];
   static_for<0, NCH>([&](auto cc) {
@@ -119,12 +122,12 @@ __global__ __launch_bounds__(512, 1) void basicblock2d_kernel(BbParams p) {
   constexpr unsigned WCH = 9 * NT * NPW * 64 * 16;            // weight bytes per 16-channel chunk
 
   // ---- 2. conv1: this wave's M-tiles w, w + 8 of the linearised 10 x 34 intermediate box
-  constexpr int NM1 = 3;
+  constexpr int NM1 = (Cf::NMT + MG - 1) / MG;               // 3 | 2
   int xbase[NM1];
   bool mt_on[NM1];
 #pragma unroll
   for (int m = 0; m < NM1; ++m) {
-    const int mt = mg + 4 * m;
+    const int mt = mg + MG * m;
     mt_on[m] = mt < Cf::NMT;                                  // wave-uniform
     const int v = min(32 * mt + r, NMID - 1);
     xbase[m] = ((v / MX) * BX + v % MX) * PITCH + h * 16;     // input voxel of tap (0, 0)
@@ -180,13 +183,13 @@ __global__ __launch_bounds__(512, 1) void basicblock2d_kernel(BbParams p) {
 #pragma unroll
   for (int m = 0; m < NM1; ++m) {
     if (!mt_on[m]) continue;
-    const int v = 32 * (mg + 4 * m) + r;
+    const int v = 32 * (mg + MG * m) + r;
     const int y = ty0 - 1 + v / MX, x = tx0 - 1 + v % MX;
     const bool inside = v < NMID && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int cb = 32 * nw + 8 * g + 4 * h;
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(aff + cb), sh = *reinterpret_cast<const f32x4*>(aff + 64 + cb);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(aff + cb), sh = *reinterpret_cast<const f32x4*>(aff + C + cb);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float t = fmaxf(acc1[m][4 * g + i] * sc[i] + sh[i], 0.f);
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(512, 1) void basicblock2d_kernel(BbParams p) {
 #pragma unroll
   for (int m = 0; m < NM1; ++m) {
     if (!mt_on[m] || ((DSM_BB_OFF & 16) && p.B != 12345)) continue;
-    const int v = 32 * (mg + 4 * m) + r;        // slots 340 .. 351 of the last tile: zeros, never read as real voxels
+    const int v = 32 * (mg + MG * m) + r;       // slots 340 .. 351 of the last tile: zeros, never read as real voxels
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       // channels 32 nw + 8 g + 4 h + i: chunk 2 nw + (g >> 1), byte 2 (8 (g & 1) + 4 h) of the voxel's 32
@@ -223,12 +226,13 @@ __global__ __launch_bounds__(512, 1) void basicblock2d_kernel(BbParams p) {
   __syncthreads();
 
   // ---- 4. conv2 from T: wave w = output row w, both 32-channel blocks
-  f32x16 acc2[2];
+  constexpr int R2 = 8 / MG;                    // output rows per wave: 2 | 1
+  f32x16 acc2[R2];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < R2; ++m)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc2[m][i] = 0.f;
-  const int tbase = ((2 * mg) * MX + r) * PITCH + h * 16;
+  const int tbase = ((R2 * mg) * MX + r) * PITCH + h * 16;
   static_for<0, NCH>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     static_for<0, 9>([&](auto ic) {
@@ -236,15 +240,15 @@ __global__ __launch_bounds__(512, 1) void basicblock2d_kernel(BbParams p) {
       constexpr int tap_off = ((item / 3) * MX + item % 3) * PITCH;
       if constexpr (item + AHEAD - 1 < 9) wload(w2rs, std::integral_constant<int, item + AHEAD - 1>{}, c * WCH);
       else if constexpr (c + 1 < NCH) wload(w2rs, std::integral_constant<int, item + AHEAD - 1 - 9>{}, (c + 1) * WCH);
-      frag xq[2][NP];
+      frag xq[R2][NP];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < R2; ++m)
 #pragma unroll
         for (int q = 0; q < NP; ++q)
           xq[m][q] = *reinterpret_cast<const frag*>(timg + c * TCH + tbase + m * (MX * PITCH) + tap_off + q * 32);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < R2; ++m)
         if (!(DSM_BB_OFF & 2) || p.B == 12345) mma32<PM>(acc2[m], wq[item % AHEAD], xq[m]);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -258,38 +262,38 @@ __global__ __launch_bounds__(512, 1) void basicblock2d_kernel(BbParams p) {
     Affine af;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      af.sc[g] = *reinterpret_cast<const f32x4*>(aff + 128 + 32 * nw + 8 * g + 4 * h) * so2;
-      af.sh[g] = *reinterpret_cast<const f32x4*>(aff + 192 + 32 * nw + 8 * g + 4 * h);
+      af.sc[g] = *reinterpret_cast<const f32x4*>(aff + 2 * C + 32 * nw + 8 * g + 4 * h) * so2;
+      af.sh[g] = *reinterpret_cast<const f32x4*>(aff + 3 * C + 32 * nw + 8 * g + 4 * h);
     }
-    Residual rr[2];
+    Residual rr[R2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int yo = ty0 + 2 * mg + m;
-      if (yo < p.H) load_residual(rr[m], p.x + (((long)b * p.H + yo) * p.W + xo) * 64 + 32 * nw + 4 * h);
+    for (int m = 0; m < R2; ++m) {
+      const int yo = ty0 + R2 * mg + m;
+      if (yo < p.H) load_residual(rr[m], p.x + (((long)b * p.H + yo) * p.W + xo) * C + 32 * nw + 4 * h);
     }
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int yo = ty0 + 2 * mg + m;
+    for (int m = 0; m < R2; ++m) {
+      const int yo = ty0 + R2 * mg + m;
       if (yo < p.H)
-        store_tile<64>(acc2[m], af, 0, p.y + (((long)b * p.H + yo) * p.W + xo) * 64 + 32 * nw + 4 * h, rr[m], true, am);
+        store_tile<C>(acc2[m], af, p.relu, p.y + (((long)b * p.H + yo) * p.W + xo) * C + 32 * nw + 4 * h, rr[m], true, am);
     }
   }
   flush_amax8(p.y_amax, am, red + 8);
 }
 
-template <int PM>
+template <int PM, int C>
 int launch_basicblock2d(BbParams p, hipStream_t s) {
-  using Cf = BbCfg<PM>;
+  using Cf = BbCfg<PM, C>;
   p.ntx = dsm_cdiv(p.W, 32); p.nty = dsm_cdiv(p.H, Cf::TY);
   const long nt = (long)p.B * p.nty * p.ntx;
   if (nt >= (1L << 30)) return DSM_ERR_UNSUPPORTED;
   p.ntiles = (int)nt;
   static thread_local bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute((const void*)basicblock2d_kernel<PM>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)basicblock2d_kernel<PM, C>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) != hipSuccess)
       return DSM_ERR_LAUNCH;
     configured = true;
   }
-  hipLaunchKernelGGL(basicblock2d_kernel<PM>, dim3((unsigned)nt), dim3(Cf::THREADS), Cf::LDS, s, p);
+  hipLaunchKernelGGL((basicblock2d_kernel<PM, C>), dim3((unsigned)nt), dim3(Cf::THREADS), Cf::LDS, s, p);
   return dsm_launch_status();
 }

@@ -1152,11 +1152,13 @@ extern "C" int dsm_conv3d_plan(const dsm_conv3d_args* a, char* buf, int len) {
 
 extern "C" int dsm_basicblock2d_fwd(const dsm_basicblock2d_args* a, dsm_stream_t stream) {
   DSM_REQUIRE(a && a->x && a->y && a->w1_packed && a->w2_packed && a->x_amax, DSM_ERR_ARG);
-  DSM_REQUIRE(a->C == 64 && a->B > 0 && a->H > 0 && a->W > 0, DSM_ERR_UNSUPPORTED);
+  DSM_REQUIRE((a->C == 64 || a->C == 32) && a->B > 0 && a->H > 0 && a->W > 0, DSM_ERR_UNSUPPORTED);
   DSM_REQUIRE(a->precision == DSM_PREC_F16X2 || a->precision == DSM_PREC_F16, DSM_ERR_UNSUPPORTED);
-  const unsigned long xb = 4ul * a->B * a->H * a->W * 64;
+  DSM_REQUIRE(a->relu == 0 || a->relu == 1, DSM_ERR_ARG);
+  const int C = a->C;
+  const unsigned long xb = 4ul * a->B * a->H * a->W * C;
   DSM_REQUIRE(xb < 0x80000000ul, DSM_ERR_UNSUPPORTED);            // 32-bit offsets, out-of-range marker at 2^31
-  const size_t sec3 = (size_t)64 * 64 * 9 * 4 + bf16x3_section_bytes(64, 64, 1, 3);
+  const size_t sec3 = (size_t)C * C * 9 * 4 + bf16x3_section_bytes(C, C, 1, 3);
   BbParams p;
   p.x = (const float*)a->x; p.y = (float*)a->y;
   p.w1_amax = (const float*)((const char*)a->w1_packed + sec3);
@@ -1165,9 +1167,9 @@ extern "C" int dsm_basicblock2d_fwd(const dsm_basicblock2d_args* a, dsm_stream_t
   p.w2 = (const unsigned char*)a->w2_packed + sec3 + 16;
   p.scale1 = a->scale1; p.shift1 = a->shift1; p.scale2 = a->scale2; p.shift2 = a->shift2;
   p.x_amax = a->x_amax; p.y_amax = a->y_amax;
-  p.B = a->B; p.H = a->H; p.W = a->W; p.ntx = p.nty = p.ntiles = 0;
+  p.B = a->B; p.H = a->H; p.W = a->W; p.C = C; p.relu = a->relu; p.ntx = p.nty = p.ntiles = 0;
   p.xbytes = (unsigned)xb;
-  p.wbytes = (unsigned)(f16_section_bytes(64, 64, 1, 3) - 16);
+  p.wbytes = (unsigned)(f16_section_bytes(C, C, 1, 3) - 16);
   dsm_clear_stale_error();
   return dsmk::run_basicblock_f16(a->precision == DSM_PREC_F16X2 ? 2 : 1, p, (hipStream_t)stream);
 }

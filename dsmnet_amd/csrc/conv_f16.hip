@@ -29,7 +29,7 @@ int dsmk::run_split_f16(const Plan& pl, const ConvParams& p, hipStream_t s) {
 }
 
 int dsmk::run_basicblock_f16(int pm, const BbParams& p, hipStream_t s) {
-  if (pm == 2) return launch_basicblock2d<2>(p, s);
-  if (pm == 1) return launch_basicblock2d<1>(p, s);
+  if (pm == 2) return p.C == 64 ? launch_basicblock2d<2, 64>(p, s) : launch_basicblock2d<2, 32>(p, s);
+  if (pm == 1) return p.C == 64 ? launch_basicblock2d<1, 64>(p, s) : launch_basicblock2d<1, 32>(p, s);
   return DSM_ERR_UNSUPPORTED;
 }

@@ -116,9 +116,14 @@ class BasicBlock(nn.Module):
         if x.is_cuda and not self.training and not torch.is_grad_enabled():
             # eval on the GPU: both 3x3 convolutions on the MFMA kernel (blocks2d), BN folded,
             # ReLU and the skip addition in their epilogues -- two launches per block
-            from ..blocks2d import _Folded2d, run_conv2d
+            from ..blocks2d import _Folded2d, run_conv2d, run_basicblock_layers
             if not hasattr(self, "_folds"):
                 self._folds = (_Folded2d(), _Folded2d())
+            if self.downsample is None:             # both convolutions, the add and the ReLU in ONE launch
+                y = run_basicblock_layers(self._folds[0], self.conv1, self.bn1, self._folds[1], self.conv2,
+                                          self.bn2, x, True)
+                if y is not None:
+                    return y
             skip = x if self.downsample is None else self.downsample(x)
             y = run_conv2d(self._folds[0], self.conv1, self.bn1, x, relu=True)
             return run_conv2d(self._folds[1], self.conv2, self.bn2, y, residual=skip, relu=True)

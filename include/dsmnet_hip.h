@@ -210,11 +210,11 @@ int dsm_conv_pack_weights(const void* w_torch, void* w_packed, int Cin_src, int 
  * zeroes it first): the `x_amax` of a tensor no launch of this library produced. */
 int dsm_absmax(const void* x, size_t n, float* amax, dsm_stream_t stream);
 
-/* Two convolutions per launch: the stride-1 64-channel BasicBlock of PSMNet's towers
- * (models/psmnet/submodule.py:24-46):  y = BN2(conv2(ReLU(BN1(conv1(x))))) + x,  both Conv2d(64, 64, 3,
- * stride 1, pad 1), folded BatchNorm as scale / shift per channel (NULL: 1 / 0).  x, y: fp32 NHWC
- * (B, H, W, 64); w1_packed, w2_packed: dsm_conv_pack_weights buffers of the two layers (Cin = Cout = 64,
- * kd = 1, k = 3).  precision: DSM_PREC_F16X2 or DSM_PREC_F16 (the fp16 modes only); x_amax as in
+/* Two convolutions per launch: the stride-1 BasicBlock of PSMNet's towers (models/psmnet/submodule.py:24-46;
+ * C = 64 or 32) and of GCNet's (models/util_conv.py:181-210; C = 32, relu = 1):
+ * y = [ReLU](BN2(conv2(ReLU(BN1(conv1(x))))) + x),  both Conv2d(C, C, 3, stride 1, pad 1), folded BatchNorm as
+ * scale / shift per channel (NULL: 1 / 0); relu = 1: ReLU after the skip add.  x, y: fp32 NHWC (B, H, W, C);
+ * w1_packed, w2_packed: dsm_conv_pack_weights buffers of the two layers (Cin = Cout = C, kd = 1, k = 3).  precision: DSM_PREC_F16X2 or DSM_PREC_F16 (the fp16 modes only); x_amax as in
  * dsm_conv3d_args (required), y_amax optional.  The intermediate map never leaves the chip; it is scaled
  * for its fp16 split by each tile's own maximum.  Eval mode only (no backward). */
 typedef struct {
@@ -224,6 +224,7 @@ typedef struct {
   const float* x_amax; float* y_amax;
   int B, H, W, C;
   int precision;
+  int relu;
 } dsm_basicblock2d_args;
 int dsm_basicblock2d_fwd(const dsm_basicblock2d_args* a, dsm_stream_t stream);
 

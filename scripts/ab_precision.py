@@ -21,6 +21,7 @@ LAYERS = [
     ("2d 32->32 192x640 x8", "2d", 32, 32, 1, False, 1, (2, 192, 640)),
     ("2d 64->64 96x320 x31", "2d", 64, 64, 1, False, 1, (2, 96, 320)),
     ("bb 64->64->64 96x320 x15", "bb", 64, 64, 1, False, 1, (2, 96, 320)),
+    ("bb 32->32->32 192x640 x3", "bb", 32, 32, 1, False, 1, (2, 192, 640)),
     ("2d 128->128 96x320 x7", "2d", 128, 128, 1, False, 1, (2, 96, 320)),
     ("2d 128->128 dil2 x6", "2d", 128, 128, 1, False, 2, (2, 96, 320)),
     ("2d 320->128 lastconv", "2d", 320, 128, 1, False, 1, (2, 96, 320)),

@@ -16,7 +16,8 @@ for l in rows[2:]:
 # rocprof's kernel name -> the plan name bench.py reports
 NAMES = {
     "conv_zs_kernel<2>": "conv3d_zs_f16x2_mfma_kernel",
-    "basicblock2d_kernel<2>": "basicblock2d_f16x2_mfma_kernel",
+    "basicblock2d_kernel<2, 64>": "basicblock2d_f16x2_mfma_kernel<C=64>",
+    "basicblock2d_kernel<2, 32>": "basicblock2d_f16x2_mfma_kernel<C=32>",
     "conv_once_kernel<2, 1, 2, 4, 2>": "conv2d_f16x2_mfma_kernel<NT=1,TM=2,DIL=1>x2,once",
     "conv_split_kernel<2, 1, 2, 1, 1, 1, 2>": "conv2d_f16x2_mfma_kernel<NT=1,TM=2,DIL=1>x2",
     "conv_split_kernel<2, 2, 2, 1, 1, 1, 2>": "conv2d_f16x2_mfma_kernel<NT=2,TM=2,DIL=1>x2",

@@ -41,9 +41,9 @@ def plan_name(n):
             return "conv3d_%s_mfma_kernel<S=2,NT=%d,TM=%d>" % (pr, NT, TM)
         return ("conv3d_%s_mfma_kernel<NT=%d,TM=%d>" % (pr, NT, TM) if KZ == 3 else
                 "conv2d_%s_mfma_kernel<NT=%d,TM=%d,DIL=%d>" % (pr, NT, TM, DIL))
-    m = re.match(r"basicblock2d_kernel<(\d+)>", n)
+    m = re.match(r"basicblock2d_kernel<(\d+), (\d+)>", n)
     if m:
-        return "basicblock2d_%s_mfma_kernel" % PR[m.group(1)]
+        return "basicblock2d_%s_mfma_kernel<C=%s>" % (PR[m.group(1)], m.group(2))
     m = re.match(r"conv_once_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", n)
     if m:
         return "conv2d_%s_mfma_kernel<NT=%s,TM=%s,DIL=1>x%s,once" % (PR[m.group(1)], m.group(2), m.group(3), m.group(5))
