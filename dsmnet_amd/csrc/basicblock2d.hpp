@@ -47,12 +47,16 @@ struct BbCfg {
   static constexpr int PITCH = 32 * NP + 16;
   static constexpr int XIMG = NPF * 128 * PITCH;             // 512 voxel slots
   static constexpr int TCH = NMT * 32 * PITCH;               // one 16-channel chunk of T (352 voxel slots)
-  static constexpr int LDS = XIMG + NCH * TCH + 4 * C * 4 + 64;
+  // T takes over X's bytes: X is dead when conv1 is done (the barrier of the tile-maximum reduction
+  // stands between its last read and T's first write)
+  static constexpr int IMGS = XIMG > NCH * TCH ? XIMG : NCH * TCH;
+  static constexpr int LDS = IMGS + 4 * C * 4 + 64;        // 111.7 KB (C = 64) | 57.0 KB (C = 32: two workgroups per CU)
+  static constexpr int WGS = 2 * LDS <= 160 * 1024 ? 2 : 1;
   static_assert(LDS <= 160 * 1024, "LDS");
 };
 
 template <int PM, int C>
-__global__ __launch_bounds__(512, 1) void basicblock2d_kernel(BbParams p) {
+__global__ __launch_bounds__(512, (BbCfg<PM, C>::WGS)) void basicblock2d_kernel(BbParams p) {
   using Cf = BbCfg<PM, C>;
   using frag = typename Prec<PM>::frag;
   constexpr int NP = Cf::NP, NPW = Cf::NPW, NCH = Cf::NCH, NT = Cf::NT, TY = Cf::TY, BX = Cf::BX, MX = Cf::MX,
@@ -60,8 +64,8 @@ __global__ __launch_bounds__(512, 1) void basicblock2d_kernel(BbParams p) {
   constexpr int AHEAD = 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* const ximg = lds_raw;
-  unsigned char* const timg = lds_raw + XIMG;
-  float* const aff = reinterpret_cast<float*>(lds_raw + XIMG + NCH * TCH);   // scale1, shift1, scale2, shift2
+  unsigned char* const timg = lds_raw;          // (aliases X, see BbCfg)
+  float* const aff = reinterpret_cast<float*>(lds_raw + Cf::IMGS);           // scale1, shift1, scale2, shift2
   float* const red = aff + 4 * C;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
