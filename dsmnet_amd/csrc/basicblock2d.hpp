@@ -178,6 +178,16 @@ __global__ __launch_bounds__(512, (BbCfg<PM, C>::WGS)) void basicblock2d_kernel(
       __builtin_amdgcn_sched_barrier(0);
     });
   });
+  // the skip values of this wave's output rows: requested now, needed after conv2 (requested in the
+  // epilogue they cost a memory latency with nothing left to hide it: 1.2 us of 39)
+  constexpr int R2 = 8 / MG;                    // output rows per wave: 2 | 1
+  const int xo = tx0 + r;
+  Residual rr[R2];
+#pragma unroll
+  for (int m = 0; m < R2; ++m) {
+    const int yo = ty0 + R2 * mg + m;
+    if (xo < p.W && yo < p.H) load_residual(rr[m], p.x + (((long)b * p.H + yo) * p.W + xo) * C + 32 * nw + 4 * h);
+  }
   // conv2's first weights ride behind the intermediate's processing
   const __amdgpu_buffer_rsrc_t w2rs = make_rsrc(p.w2, p.wbytes);
   static_for<0, AHEAD - 1>([&](auto ic) { wload(w2rs, ic, 0u); });
@@ -230,7 +240,6 @@ __global__ __launch_bounds__(512, (BbCfg<PM, C>::WGS)) void basicblock2d_kernel(
   __syncthreads();
 
   // ---- 4. conv2 from T: wave w = output row w, both 32-channel blocks
-  constexpr int R2 = 8 / MG;                    // output rows per wave: 2 | 1
   f32x16 acc2[R2];
 #pragma unroll
   for (int m = 0; m < R2; ++m)
@@ -260,7 +269,6 @@ __global__ __launch_bounds__(512, (BbCfg<PM, C>::WGS)) void basicblock2d_kernel(
 
   // ---- 5. BN2 with the tile's factor, + x, store
   float am = 0.f;
-  const int xo = tx0 + r;
   if (xo < p.W && (!(DSM_BB_OFF & 8) || p.B == 12345)) {
     const float so2 = dsm_pow2f(-(et + ew2));
     Affine af;
@@ -268,12 +276,6 @@ __global__ __launch_bounds__(512, (BbCfg<PM, C>::WGS)) void basicblock2d_kernel(
     for (int g = 0; g < 4; ++g) {
       af.sc[g] = *reinterpret_cast<const f32x4*>(aff + 2 * C + 32 * nw + 8 * g + 4 * h) * so2;
       af.sh[g] = *reinterpret_cast<const f32x4*>(aff + 3 * C + 32 * nw + 8 * g + 4 * h);
-    }
-    Residual rr[R2];
-#pragma unroll
-    for (int m = 0; m < R2; ++m) {
-      const int yo = ty0 + R2 * mg + m;
-      if (yo < p.H) load_residual(rr[m], p.x + (((long)b * p.H + yo) * p.W + xo) * C + 32 * nw + 4 * h);
     }
 #pragma unroll
     for (int m = 0; m < R2; ++m) {
