@@ -85,7 +85,7 @@ SIGNATURES = {
     "dsm_spp_branch_floats": (ctypes.c_size_t, [c_int] * 3),
     "dsm_spp_pool8": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "dsm_spp_branches": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
-    "dsm_spp_concat": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
+    "dsm_spp_concat": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 2),
     "dsm_warp_abs_error": (c_int, [c_void_p] * 4 + [c_int] * 6 + [ctypes.c_float, c_void_p]),
 }
 

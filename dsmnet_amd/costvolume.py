@@ -775,8 +775,11 @@ def spp_head(raw, skip, w_t, scale, shift):
                                       _stream())
         _lib.check(rc, "dsm_spp_branches")
         with _timed("spp_concat_kernel", 4.0 * (raw.numel() + skip.numel() + out.numel())):
-            rc = lib.dsm_spp_concat(_p(raw), _p(skip), _p(br), _p(out), B, H, W, _stream())
+            ya = _ARENA.slot(out.device) if needs_amax() else None     # lastconv's x_amax, without a pass of its own
+            rc = lib.dsm_spp_concat(_p(raw), _p(skip), _p(br), _p(out), B, H, W, _p(ya), _stream())
         _lib.check(rc, "dsm_spp_concat")
+    if ya is not None:
+        out._dsm_amax = ya
     return out
 
 

@@ -119,12 +119,16 @@ __device__ __forceinline__ Tap tap_at(int o, int in_size, int out_size) {
 // passes over the pixel's 80 16-byte quads -- 256 contiguous bytes per pixel and pass, the pixel's
 // coordinates and bilinear taps computed once, 32-bit index arithmetic (the first form, one flat
 // 64-bit index per quad with a division by 80 and by W, H each, spent its time in integer division).
+__device__ __forceinline__ float quad_amax(const f32x4 v) {
+  return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
 __global__ __launch_bounds__(256) void spp_concat_kernel(const float* __restrict__ raw,
                                                          const float* __restrict__ skip,
                                                          const float* __restrict__ br,
                                                          float* __restrict__ out, int B, int H,
-                                                         int W, int h8, int w8) {
+                                                         int W, int h8, int w8, float* __restrict__ y_amax) {
   constexpr int NQ = C_OUT / 4;
+  float am = 0.f;               // max |out| of this thread's quads (the fp16 convolution modes' x_amax of lastconv)
   const BranchGeo g = branch_geo(B, h8, w8);
   const int npix = B * H * W;                                    // < 2^31: checked by the host
   const int lp = threadIdx.x >> 4, lq = threadIdx.x & 15;
@@ -132,9 +136,11 @@ __global__ __launch_bounds__(256) void spp_concat_kernel(const float* __restrict
     const int x = pix % W, y = (pix / W) % H, b = pix / (W * H);
     f32x4* dst = reinterpret_cast<f32x4*>(out) + (long)pix * NQ;
     // passes 0 (raw: quads 0..15), 1..2 (skip: quads 16..47)
-    dst[lq] = reinterpret_cast<const f32x4*>(raw + (long)pix * C_RAW)[lq];
-    dst[16 + lq] = reinterpret_cast<const f32x4*>(skip + (long)pix * C_SKIP)[lq];
-    dst[32 + lq] = reinterpret_cast<const f32x4*>(skip + (long)pix * C_SKIP)[16 + lq];
+    const f32x4 c0 = reinterpret_cast<const f32x4*>(raw + (long)pix * C_RAW)[lq];
+    const f32x4 c1 = reinterpret_cast<const f32x4*>(skip + (long)pix * C_SKIP)[lq];
+    const f32x4 c2 = reinterpret_cast<const f32x4*>(skip + (long)pix * C_SKIP)[16 + lq];
+    dst[lq] = c0; dst[16 + lq] = c1; dst[32 + lq] = c2;
+    am = fmaxf(fmaxf(fmaxf(am, quad_amax(c0)), quad_amax(c1)), quad_amax(c2));
     // passes 3..4: quads 48..79 = four branches x 8 quads
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -146,7 +152,21 @@ __global__ __launch_bounds__(256) void spp_concat_kernel(const float* __restrict
       const f32x4 v01 = m[(ty.i0 * wb + tx.i1) * (C_BR / 4)];
       const f32x4 v10 = m[(ty.i1 * wb + tx.i0) * (C_BR / 4)];
       const f32x4 v11 = m[(ty.i1 * wb + tx.i1) * (C_BR / 4)];
-      dst[48 + bq] = ty.w0 * (tx.w0 * v00 + tx.w1 * v01) + ty.w1 * (tx.w0 * v10 + tx.w1 * v11);
+      const f32x4 v = ty.w0 * (tx.w0 * v00 + tx.w1 * v01) + ty.w1 * (tx.w0 * v10 + tx.w1 * v11);
+      dst[48 + bq] = v;
+      am = fmaxf(am, quad_amax(v));
+    }
+  }
+  if (y_amax) {                 // uniform: one atomic per workgroup, none when the slot already holds as much
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      if (am > __builtin_nontemporal_load(y_amax))
+        atomicMax(reinterpret_cast<unsigned*>(y_amax), __builtin_bit_cast(unsigned, am));
     }
   }
 }
@@ -187,7 +207,7 @@ extern "C" int dsm_spp_branches(const void* p8, const void* w_t, const void* sca
 }
 
 extern "C" int dsm_spp_concat(const void* raw, const void* skip, const void* branches, void* out,
-                              int B, int H, int W, dsm_stream_t stream) {
+                              int B, int H, int W, float* y_amax, dsm_stream_t stream) {
   DSM_REQUIRE(raw && skip && branches && out, DSM_ERR_ARG);
   DSM_REQUIRE(B > 0 && H >= 64 && W >= 64, DSM_ERR_ARG);
   DSM_REQUIRE(dsm_aligned16(raw) && dsm_aligned16(skip) && dsm_aligned16(branches) &&
@@ -198,6 +218,6 @@ extern "C" int dsm_spp_concat(const void* raw, const void* skip, const void* bra
   dsm_clear_stale_error();
   hipLaunchKernelGGL(spp_concat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      (const float*)raw, (const float*)skip, (const float*)branches, (float*)out,
-                     B, H, W, H / 8, W / 8);
+                     B, H, W, H / 8, W / 8, y_amax);
   return dsm_launch_status();
 }

@@ -339,7 +339,8 @@ int dsm_spp_pool8(const void* skip, void* p8, int B, int H, int W, dsm_stream_t 
 int dsm_spp_branches(const void* p8, const void* w_t, const void* scale, const void* shift,
                      void* branches, int B, int h8, int w8, dsm_stream_t stream);
 int dsm_spp_concat(const void* raw, const void* skip, const void* branches, void* out,
-                   int B, int H, int W, dsm_stream_t stream);
+                   int B, int H, int W, float* y_amax /* NULL, or the device scalar raised to max |out| (ABI v7) */,
+                   dsm_stream_t stream);
 
 /* Disparity warp, optionally fused with the reconstruction error -- utils/imwrap.py:37-72
  * (imwrap_BCHW with its default arguments) and models/iresnet.py:169-170.

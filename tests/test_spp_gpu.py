@@ -38,3 +38,22 @@ def test_spp_head_rejects_small_maps(hip_lib):
     a = torch.zeros(4, 32, device="cuda")
     with pytest.raises(ValueError):
         cv.spp_head(raw, skip, w, a, a)
+
+
+def test_spp_concat_reports_its_maximum(hip_lib):
+    """The concat kernel raises the device scalar the fp16 convolution modes read as lastconv's x_amax
+    (no separate pass over the 320-channel map)."""
+    import torch
+    from dsmnet_amd import costvolume as cv
+    from tests.helpers import seeded
+    old = cv.set_option("conv_precision", "f16x2")
+    try:
+        raw = seeded(3, 2, 64, 64, 96).cuda().contiguous(memory_format=torch.channels_last)
+        skip = seeded(4, 2, 128, 64, 96).cuda().contiguous(memory_format=torch.channels_last)
+        w_t = seeded(5, 4, 128, 32).cuda()
+        scale, shift = (seeded(6, 4, 32).abs() + 0.5).cuda(), seeded(7, 4, 32).cuda()
+        with cv.amax_scope(raw.device):
+            out = cv.spp_head(raw, skip, w_t, scale, shift)
+            assert out._dsm_amax.item() == out.abs().max().item()
+    finally:
+        cv.set_option("conv_precision", old)
