@@ -52,7 +52,7 @@ class BasicBlock2dArgs(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("y", c_void_p), ("w1_packed", c_void_p), ("w2_packed", c_void_p),
                 ("scale1", c_void_p), ("shift1", c_void_p), ("scale2", c_void_p), ("shift2", c_void_p),
                 ("x_amax", c_void_p), ("y_amax", c_void_p),
-                ("B", c_int), ("H", c_int), ("W", c_int), ("C", c_int), ("precision", c_int), ("relu", c_int)]
+                ("B", c_int), ("H", c_int), ("W", c_int), ("C", c_int), ("precision", c_int), ("relu", c_int), ("no_skip", c_int)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in dsmnet_hip.h

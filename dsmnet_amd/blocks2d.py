@@ -164,7 +164,7 @@ def run_conv2d(folded, conv, bn, x, residual=None, relu=False):
     return F.relu(y) if relu else y
 
 
-def run_basicblock_layers(fold1, c1, b1, fold2, c2, b2, x, relu_after):
+def run_basicblock_layers(fold1, c1, b1, fold2, c2, b2, x, relu_after, skip=True):
     """``bn2(conv2(relu(bn1(conv1(x))))) + x`` (``relu_after``: ReLU after the add) as ONE launch where
     ``costvolume.basicblock2d`` covers it -- eval mode on the GPU, no gradient, two stride-1 3x3
     convolutions of 32 or 64 channels, each with its BatchNorm -- else None (the caller runs the two
@@ -177,7 +177,7 @@ def run_basicblock_layers(fold1, c1, b1, fold2, c2, b2, x, relu_after):
         return None
     p1, s1, h1 = fold1.get(c1, b1, x.shape[1])
     p2, s2, h2 = fold2.get(c2, b2, x.shape[1])
-    return cv.basicblock2d(x, p1, s1, h1, p2, s2, h2, relu=relu_after)
+    return cv.basicblock2d(x, p1, s1, h1, p2, s2, h2, relu=relu_after, skip=skip)
 
 
 def run_basicblock(cb1, cb2, x, downsample):

@@ -680,10 +680,11 @@ def basicblock2d_ok(x, cin, cout, stride, dilation):
             4 * x.numel() < 2 ** 31)
 
 
-def basicblock2d(x, packed1, scale1, shift1, packed2, scale2, shift2, relu=False):
+def basicblock2d(x, packed1, scale1, shift1, packed2, scale2, shift2, relu=False, skip=True):
     """``conv2(relu(conv1(x) * scale1 + shift1)) * scale2 + shift2 + x`` (``relu``: ReLU after the add)
     on an NHWC map with 64 or 32 channels, both convolutions 3x3 / stride 1 / pad 1
-    (models/psmnet/submodule.py:24-46, models/util_conv.py:181-210 with the BatchNorms folded): one
+    (models/psmnet/submodule.py:24-46, models/util_conv.py:181-210 with the BatchNorms folded;
+    ``skip=False``: no ``+ x`` -- two convbn + ReLU layers in a row): one
     launch, the intermediate map stays in LDS.  ``packed*``: the layers' ``pack_conv2d_weight``
     buffers.  Inference only; fp16 modes only."""
     _require_device("basicblock2d", x, packed1, packed2, scale1, shift1, scale2, shift2)
@@ -703,6 +704,7 @@ def basicblock2d(x, packed1, scale1, shift1, packed2, scale2, shift2, relu=False
     a.shift2 = None if shift2 is None else shift2.data_ptr()
     a.B, a.H, a.W, a.C = B, H, W, C
     a.relu = 1 if relu else 0
+    a.no_skip = 0 if skip else 1
     a.precision = _lib.DSM_PREC_F16X2 if mode == "f16x2" else _lib.DSM_PREC_F16
     xa = amax_of(x)
     ya = _ARENA.slot(y.device)

@@ -1,6 +1,7 @@
 // Two convolutions per launch: the stride-1 BasicBlock of PSMNet's towers (models/psmnet/submodule.py:24-46;
 // C = 64: layer2, C = 32: layer1) and of GCNet's (models/util_conv.py:181-210; C = 32, ReLU after the add),
-//   y = [ReLU](BN2(conv2(ReLU(BN1(conv1(x))))) + x),   conv1, conv2 = Conv2d(C, C, 3, stride 1, pad 1),
+//   y = [ReLU](BN2(conv2(ReLU(BN1(conv1(x))))) [+ x]),   conv1, conv2 = Conv2d(C, C, 3, stride 1, pad 1)
+// (without the skip: two convbn + ReLU in a row, PSMNet's firstconv[2..5], submodule.py:81-86),
 // with the intermediate map kept in LDS.  Included by conv_f16.hip (fp16 modes) after conv_split.hpp.
 //
 // Why: the towers' 64-channel layers run ONE round of workgroups per launch, whose load, multiply and
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(512, (BbCfg<PM, C>::WGS)) void basicblock2d_kernel(
 #pragma unroll
   for (int m = 0; m < R2; ++m) {
     const int yo = ty0 + R2 * mg + m;
-    if (xo < p.W && yo < p.H) load_residual(rr[m], p.x + (((long)b * p.H + yo) * p.W + xo) * C + 32 * nw + 4 * h);
+    if (p.skip && xo < p.W && yo < p.H) load_residual(rr[m], p.x + (((long)b * p.H + yo) * p.W + xo) * C + 32 * nw + 4 * h);
   }
   // conv2's first weights ride behind the intermediate's processing
   const __amdgpu_buffer_rsrc_t w2rs = make_rsrc(p.w2, p.wbytes);
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(512, (BbCfg<PM, C>::WGS)) void basicblock2d_kernel(
     for (int m = 0; m < R2; ++m) {
       const int yo = ty0 + R2 * mg + m;
       if (yo < p.H)
-        store_tile<C>(acc2[m], af, p.relu, p.y + (((long)b * p.H + yo) * p.W + xo) * C + 32 * nw + 4 * h, rr[m], true, am);
+        store_tile<C>(acc2[m], af, p.relu, p.y + (((long)b * p.H + yo) * p.W + xo) * C + 32 * nw + 4 * h, rr[m], p.skip != 0, am);
     }
   }
   flush_amax8(p.y_amax, am, red + 8);

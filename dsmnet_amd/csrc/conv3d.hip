@@ -1167,7 +1167,7 @@ extern "C" int dsm_basicblock2d_fwd(const dsm_basicblock2d_args* a, dsm_stream_t
   p.w2 = (const unsigned char*)a->w2_packed + sec3 + 16;
   p.scale1 = a->scale1; p.shift1 = a->shift1; p.scale2 = a->scale2; p.shift2 = a->shift2;
   p.x_amax = a->x_amax; p.y_amax = a->y_amax;
-  p.B = a->B; p.H = a->H; p.W = a->W; p.C = C; p.relu = a->relu; p.ntx = p.nty = p.ntiles = 0;
+  p.B = a->B; p.H = a->H; p.W = a->W; p.C = C; p.relu = a->relu; p.skip = a->no_skip ? 0 : 1; p.ntx = p.nty = p.ntiles = 0;
   p.xbytes = (unsigned)xb;
   p.wbytes = (unsigned)(f16_section_bytes(C, C, 1, 3) - 16);
   dsm_clear_stale_error();

@@ -57,7 +57,7 @@ struct BbParams {
   const float* w1_amax; const float* w2_amax;
   const float* scale1; const float* shift1; const float* scale2; const float* shift2;
   const float* x_amax; float* y_amax;
-  int B, H, W, C, relu, ntx, nty, ntiles;                 // relu: 1 = ReLU after the skip add (GCNet's block)
+  int B, H, W, C, relu, skip, ntx, nty, ntiles;           // relu: 1 = ReLU at the end (GCNet's block); skip: 1 = + x
   unsigned xbytes, wbytes;
 };
 

@@ -183,8 +183,10 @@ class feature_extraction(nn.Module):
             x = stage_image_nhwc16(x)                  # NHWC, 3 -> 16 staged channels
         elif _TRAIN_NHWC and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
-        for i in (0, 2, 4):
-            x = self.firstconv[i](x, relu=True)
+        x = self.firstconv[0](x, relu=True)
+        fc2, fc4 = self.firstconv[2], self.firstconv[4]           # two convbn + ReLU of 32 channels: one launch
+        y = blocks2d.run_basicblock_layers(fc2._folded, fc2[0], fc2[1], fc4._folded, fc4[0], fc4[1], x, True, skip=False)
+        x = y if y is not None else fc4(fc2(x, relu=True), relu=True)
         x = self.layer1(x)
         raw = self.layer2(x)
         skip = self.layer4(self.layer3(raw))

@@ -225,6 +225,7 @@ typedef struct {
   int B, H, W, C;
   int precision;
   int relu;
+  int no_skip;       /* 1: no `+ x` (two convolution + BN + ReLU layers in a row: PSMNet's firstconv) */
 } dsm_basicblock2d_args;
 int dsm_basicblock2d_fwd(const dsm_basicblock2d_args* a, dsm_stream_t stream);
 

@@ -257,11 +257,11 @@ def test_single_tile_form_of_the_64_channel_layers_gives_the_same_bits(cv, mode,
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("C,relu,hw", [(64, False, (96, 320)), (64, False, (13, 37)), (64, True, (8, 32)),
-                                       (64, False, (45, 100)), (32, True, (50, 70)), (32, False, (17, 64)),
-                                       (32, True, (64, 128))])
+@pytest.mark.parametrize("C,relu,hw,skip", [(64, False, (96, 320), True), (64, False, (13, 37), True), (64, True, (8, 32), True),
+                                            (64, False, (45, 100), True), (32, True, (50, 70), True), (32, False, (17, 64), True),
+                                            (32, True, (64, 128), True), (32, True, (40, 90), False)])
 @pytest.mark.parametrize("mode", ["f16x2", "f16"])
-def test_basicblock_in_one_launch(cv, mode, C, relu, hw):
+def test_basicblock_in_one_launch(cv, mode, C, relu, hw, skip):
     """PSMNet's stride-1 64-channel BasicBlock (models/psmnet/submodule.py:24-46) as ONE launch with the
     intermediate map in LDS (csrc/basicblock2d.hpp), against float64 on the CPU; ragged tiles, tiles
     whose halo leaves the image on every side, maps smaller than a tile."""
@@ -272,16 +272,18 @@ def test_basicblock_in_one_launch(cv, mode, C, relu, hw):
     s1, h1 = seeded(94, C).abs() + 0.5, seeded(95, C)
     s2, h2 = seeded(96, C).abs() + 0.5, seeded(97, C)
     t = F.conv2d(x.double(), w1.double(), padding=1) * s1.double().view(1, -1, 1, 1) + h1.double().view(1, -1, 1, 1)
-    ref = F.conv2d(t.relu(), w2.double(), padding=1) * s2.double().view(1, -1, 1, 1) + h2.double().view(1, -1, 1, 1) + x.double()
+    ref = F.conv2d(t.relu(), w2.double(), padding=1) * s2.double().view(1, -1, 1, 1) + h2.double().view(1, -1, 1, 1)
+    if skip:
+        ref = ref + x.double()
     if relu:
         ref = ref.relu()
     xs = x.cuda().contiguous(memory_format=torch.channels_last)
     with precision(cv, mode):
         y = cv.basicblock2d(xs, cv.pack_conv2d_weight(w1.cuda()), s1.cuda(), h1.cuda(),
-                            cv.pack_conv2d_weight(w2.cuda()), s2.cuda(), h2.cuda(), relu=relu)
+                            cv.pack_conv2d_weight(w2.cuda()), s2.cuda(), h2.cuda(), relu=relu, skip=skip)
         # the two layers as two launches: same band, not the same bits (the intermediate's scale is per tile)
         u = cv.conv2d_block(xs, cv.pack_conv2d_weight(w1.cuda()), C, s1.cuda(), h1.cuda(), relu=1)
-        u = cv.conv2d_block(u, cv.pack_conv2d_weight(w2.cuda()), C, s2.cuda(), h2.cuda(), xs, relu=1 if relu else 0)
+        u = cv.conv2d_block(u, cv.pack_conv2d_weight(w2.cuda()), C, s2.cuda(), h2.cuda(), xs if skip else None, relu=1 if relu else 0)
     emax, erms = errors(y, ref)
     lim = (F16X2_MAX, F16X2_RMS) if mode == "f16x2" else (F16_MAX, F16_RMS)
     grow = 2.0 ** 0.5                                          # two layers' rounding
@@ -317,4 +319,4 @@ def test_psmnet_towers_use_the_fused_block(cv, golden_e2e):
         counts[fuse] = sum(v["launches"] for k, v in timer.summary().items() if k.startswith("basicblock2d"))
         for pname, p in zip(("pred3", "pred2", "pred1"), out):
             golden_e2e.compare("e2e.psmnet." + pname, p, 1e-3)
-    assert counts[True] == 18 and counts[False] == 0            # layer1's three 32-channel blocks, layer2's fifteen
+    assert counts[True] == 19 and counts[False] == 0            # firstconv[2..5], layer1's three 32-channel blocks, layer2's fifteen
