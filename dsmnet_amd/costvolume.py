@@ -547,10 +547,15 @@ def carry_amax(dst, *srcs):
 
 def _split_kernel_layer(a):
     """Does ``dsm_conv3d_fwd`` run this layer on a split-operand kernel (conv3d.hip make_plan kinds
-    5 / 6)?  3x3(x3) taps, Cin % 16 == 0, Cout a multiple of 32 up to 64 (3-D) / 128 (2-D); stride 1,
-    3-D stride 2 to 64 channels, or transposed from Cin % 32 == 0."""
+    5 / 6)?  3x3(x3) taps, Cin % 16 == 0, Cout a multiple of 32 up to 64 (3-D; 128 on small volumes at
+    stride 1) / 128 (2-D); stride 1, 3-D stride 2 to 64 channels, or transposed from Cin % 32 == 0."""
     kd, k = (a.kd or 3), (a.k or 3)
-    if k != 3 or a.Cin % 16 or a.Cout % 32 or a.Cout > (64 if kd == 3 else 128):
+    if k != 3 or a.Cin % 16 or a.Cout % 32 or a.Cout > 128:
+        return False
+    if kd == 3 and a.Cout == 128:                    # four workgroup columns of 32: small volumes, stride 1 only
+        tiles4 = a.B * a.Do * ((a.Ho + 3) // 4) * ((a.Wo + 31) // 32)
+        return (not a.transposed) and a.stride == 1 and (a.dil or 1) == 1 and tiles4 <= 128
+    if kd == 3 and a.Cout > 64:
         return False
     if a.transposed:
         return kd == 3 and a.Cin % 32 == 0

@@ -869,7 +869,7 @@ int run_conv(ConvParams p, hipStream_t s, int nsplit = 1) {
 // bf16x3 kernels cover: 3x3x3 with Cout 32/64, 3x3 with Cout 32/64/128; Cin % 16 == 0.
 size_t bf16x3_section_bytes(int Cin, int Cout, int kd, int k) {
   if (k != 3 || Cin % 16 != 0 || Cout % 32 != 0) return 0;
-  if (kd == 3 ? Cout > 64 : Cout > 128) return 0;
+  if (Cout > 128) return 0;                            // (3-D, 128 outputs: four workgroup columns of 32, small volumes only)
   return (size_t)Cin * Cout * kd * 9 * 6;
 }
 // Section 3 (same shapes): a 16-byte header {absolute maximum of the weights, 0, 0, 0} followed by
@@ -1075,6 +1075,13 @@ int make_plan_f32(const dsm_conv3d_args* a, Plan* pl) {
     // the 64-channel 3-D layers on 4-row tiles (the bottom of the hourglass: 216 tiles, one serial chain
     // of 1,296 MFMAs per wave): two columns of 32 channels halve the chain
     // (one round of tiles only: 43.0 vs 44.7 us with 216 tiles; with 432 the two columns queue: 72.5 vs 67.4)
+    // 128 output channels in 3-D (GCNet's deepest encoder layers, 6 x 8 x 16 voxels): four columns of 32 on
+    // 4-row tiles; larger volumes of that width stay on the fp32-input kernel (no NT = 4 3-D variant)
+    if (kd == 3 && NT == 4) {
+      const long t4 = (long)a->B * a->Do * dsm_cdiv(a->Ho, 4) * dsm_cdiv(a->Wo, 32);
+      if (t4 <= 128 && dil == 1) { *pl = Plan{5, 1, 1, 1, 16, 3, 3, 1}; pl->nsplit = 4; return DSM_OK; }
+      goto fp32_kernels;
+    }
     if (kd == 3 && TM == 1 && NT == 2 && !(a->flags & DSM_CONV_NO_NSPLIT) &&
         (long)a->B * a->Do * dsm_cdiv(a->Ho, 4) * dsm_cdiv(a->Wo, 32) <= 256) {
       pl->NT = 1; pl->nsplit = 2;
@@ -1086,6 +1093,7 @@ int make_plan_f32(const dsm_conv3d_args* a, Plan* pl) {
     *pl = Plan{5, 2, 2, 1, 16, 3, 3, 1};           // stride 2 on the bf16 pipe: 4-row tiles, Cout = 64
     return DSM_OK;
   }
+fp32_kernels:
   if (kd == 1) {                                   // 2-D towers: one staged slice, 16-channel chunks
     const int TM = (big && NT == 1 && a->stride == 1 && k == 3 && dil == 1) ? 2 : 1;
     *pl = Plan{0, a->stride, NT, TM, 16, 1, k, dil};

@@ -1220,6 +1220,10 @@ int dispatch_split(const Plan& pl, const ConvParams& p, hipStream_t s) {
     if (pl.KZ == 3 && pl.NT == 1 && pl.TM == 1) return run_conv_split<PM, 1, 1, 3, 1, 1, 2>(p, s);
     return DSM_ERR_UNSUPPORTED;
   }
+  if (pl.nsplit == 4) {                         // 3-D, 128 output channels on a small volume
+    if (pl.KZ == 3 && pl.NT == 1 && pl.TM == 1) return run_conv_split<PM, 1, 1, 3, 1, 1, 4>(p, s);
+    return DSM_ERR_UNSUPPORTED;
+  }
 #define DSM_CASE_SPLIT(NT_, TM_, KZ_, DIL_) \
   if (pl.NT == NT_ && pl.TM == TM_ && pl.KZ == KZ_ && pl.DIL == DIL_) return run_conv_split<PM, NT_, TM_, KZ_, DIL_>(p, s)
   DSM_CASE_SPLIT(1, 4, 3, 1); DSM_CASE_SPLIT(1, 2, 3, 1); DSM_CASE_SPLIT(2, 2, 3, 1); DSM_CASE_SPLIT(2, 1, 3, 1);

@@ -56,7 +56,7 @@ def test_argument_validation_returns_codes(hip_lib):
     a.Do, a.x = 4, 20
     assert hip_lib.dsm_conv3d_fwd(ctypes.byref(a), null) == -4          # misaligned
     assert hip_lib.dsm_conv3d_packed_weight_bytes(32, 32, 0) == 32 * 32 * 27 * (4 + 6 + 4) + 16   # fp32 fragments + 3 bf16 planes + header, 2 fp16 planes
-    assert hip_lib.dsm_conv3d_packed_weight_bytes(128, 128, 0) == 128 * 128 * 27 * 4      # no bf16x3 variant
+    assert hip_lib.dsm_conv3d_packed_weight_bytes(128, 128, 0) == 128 * 128 * 27 * (4 + 6 + 4) + 16   # (r03: four columns of 32 on small volumes)
     assert hip_lib.dsm_conv_packed_weight_bytes(128, 128, 1, 3) == 128 * 128 * 9 * (4 + 6 + 4) + 16
     assert hip_lib.dsm_conv_packed_weight_bytes(128, 32, 1, 1) == 128 * 32 * 4
     # ABI v5: weight gradients (flags argument), the 2-D entry point
