@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512, (BbCfg<PM, C>::WGS)) void basicblock2d_kernel(
   using Cf = BbCfg<PM, C>;
   using frag = typename Prec<PM>::frag;
   constexpr int NP = Cf::NP, NPW = Cf::NPW, NCH = Cf::NCH, NT = Cf::NT, TY = Cf::TY, BX = Cf::BX, MX = Cf::MX,
-                NMID = Cf::NMID, NVOX = Cf::NVOX, NPF = Cf::NPF, PITCH = Cf::PITCH, XIMG = Cf::XIMG, TCH = Cf::TCH;
+                NMID = Cf::NMID, NVOX = Cf::NVOX, NPF = Cf::NPF, PITCH = Cf::PITCH, TCH = Cf::TCH;
   constexpr int AHEAD = 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* const ximg = lds_raw;
