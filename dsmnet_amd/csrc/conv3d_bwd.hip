@@ -251,7 +251,7 @@ __global__ __launch_bounds__(NT_, 1) void wgrad_split_kernel(WgradParams p) {
   constexpr int NP = WPrec<PM>::NP;
   using frag = typename WPrec<PM>::frag;
   using G = WgradGeo<S, TY, KZ, DIL, NP>;
-  constexpr int IY = G::IY, IX = G::IX, NXV = G::NXV, NGV = G::NGV, XPL = G::XPL, GPL = G::GPL;
+  constexpr int IY = G::IY, IX = G::IX, NGV = G::NGV, XPL = G::XPL, GPL = G::GPL;
   constexpr int NTAP = G::NTAP, NACC = G::NACC;
   extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
   unsigned char* const xt = wl;                    // [plane][voxel (z, y, x)][32 ch] 16-bit
